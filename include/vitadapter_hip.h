@@ -1,0 +1,109 @@
+/*
+ * vitadapter_hip.h -- C ABI of libvitadapter_hip.so (MI355X / gfx950 only).
+ *
+ * This is the drop-in boundary of the ViT-Adapter hot path.  Every entry point takes plain
+ * device pointers + sizes + a hipStream_t passed as void*; no torch types cross it.  The
+ * Python extension module the reference imports (`import MultiScaleDeformableAttention as
+ * MSDA`, /root/reference/detection/ops/functions/ms_deform_attn_func.py:11) is a thin ctypes
+ * binding over these symbols (vit-adapter_amd/MultiScaleDeformableAttention.py); INTEGRATION.md
+ * shows the binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in _host
+ *   - tensors are dense, row-major ("contiguous"), exactly the layouts the reference asserts
+ *     (/root/reference/detection/ops/src/cuda/ms_deform_attn_cuda.cu:28-38)
+ *   - work is enqueued on `stream` and the call returns immediately (no host sync, no
+ *     allocation, graph-capturable)
+ *   - return value: 0 = success; <0 = argument error (VAH_E_*); >0 = hipError_t from the
+ *     launch.  vah_last_error() gives a thread-local human readable message.  Unlike the
+ *     reference (which only printf()s launch failures, ms_deform_im2col_cuda.cuh:948-952,
+ *     1321-1325) every failure is reported to the caller.
+ */
+#ifndef VITADAPTER_HIP_H
+#define VITADAPTER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VAH_OK 0
+#define VAH_E_NULL (-1)       /* a required pointer is NULL */
+#define VAH_E_SHAPE (-2)      /* a dimension is negative / inconsistent / too large */
+#define VAH_E_UNSUPPORTED (-3)
+#define VAH_E_ALIGN (-4)      /* a pointer misses the alignment its fast path needs */
+
+/* ABI version; bumped on any signature change. */
+int vah_abi_version(void);
+/* Thread-local message for the last non-zero return on this thread ("" if none). */
+const char *vah_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Multi-scale deformable attention  (SURVEY.md section 8 rows a-1 .. a-4)
+ *
+ * Replaces the reference's
+ *   ms_deform_attn_forward  (/root/reference/detection/ops/src/vision.cpp:14,
+ *                            ms_deform_attn.h:21-40, cuda/ms_deform_attn_cuda.cu:20-80,
+ *                            kernel cuda/ms_deform_im2col_cuda.cuh:237-299)
+ *   ms_deform_attn_backward (/root/reference/detection/ops/src/vision.cpp:15,
+ *                            ms_deform_attn.h:42-61, cuda/ms_deform_attn_cuda.cu:83-153,
+ *                            kernels cuda/ms_deform_im2col_cuda.cuh:301-920)
+ *
+ *   value    (N, S, M, D)            S = sum_l H_l*W_l
+ *   shapes   (L, 2) int64  (H_l, W_l)      -- read on the device, never copied to the host
+ *   lsi      (L,)   int64  level start row -- read on the device
+ *   loc      (N, Lq, M, L, P, 2)     (x, y) normalised to [0,1] over each level
+ *   attn     (N, Lq, M, L, P)
+ *   out      (N, Lq, M*D)            fully overwritten
+ *
+ * The reference's im2col_step only chunks the batch into separate launches and does not
+ * change results (ms_deform_attn_cuda.cu:50-75); it therefore lives in the Python binding
+ * (argument check only) and not in this ABI.
+ *
+ * Level guard: a level whose (H, W, start) read from device memory is not a valid window of
+ * the S rows (H<1, W<1, start<0, start+H*W>S) contributes nothing instead of faulting.
+ * ------------------------------------------------------------------------------------ */
+int vah_msda_forward_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                         const float *loc, const float *attn,
+                         int64_t N, int64_t S, int64_t M, int64_t D,
+                         int64_t L, int64_t Lq, int64_t P,
+                         float *out, void *stream);
+int vah_msda_forward_f64(const double *value, const int64_t *shapes, const int64_t *lsi,
+                         const double *loc, const double *attn,
+                         int64_t N, int64_t S, int64_t M, int64_t D,
+                         int64_t L, int64_t Lq, int64_t P,
+                         double *out, void *stream);
+
+/* grad_out (N, Lq, M*D).  grad_value (N,S,M,D) MUST be zero on entry (the caller allocates
+ * it zeroed exactly as the reference does, ms_deform_attn_cuda.cu:121-123) and is
+ * accumulated with float atomics (run-to-run last-bit nondeterminism, as in the reference).
+ * grad_loc (N,Lq,M,L,P,2) and grad_attn (N,Lq,M,L,P) are fully overwritten. */
+int vah_msda_backward_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                          const float *loc, const float *attn, const float *grad_out,
+                          int64_t N, int64_t S, int64_t M, int64_t D,
+                          int64_t L, int64_t Lq, int64_t P,
+                          float *grad_value, float *grad_loc, float *grad_attn, void *stream);
+int vah_msda_backward_f64(const double *value, const int64_t *shapes, const int64_t *lsi,
+                          const double *loc, const double *attn, const double *grad_out,
+                          int64_t N, int64_t S, int64_t M, int64_t D,
+                          int64_t L, int64_t Lq, int64_t P,
+                          double *grad_value, double *grad_loc, double *grad_attn, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Launch timing (bench.py's roofline leg).  While enabled, every kernel launched through
+ * this library is bracketed by two hipEvents recorded on the launch's own stream.
+ *   vah_prof_enable(1)  : start collecting (drops anything collected before)
+ *   vah_prof_enable(0)  : stop collecting
+ *   vah_prof_report(..) : synchronises the recorded events and writes one text line per
+ *                         kernel name:  "<name> <calls> <total_ms> <algorithmic_bytes>\n"
+ *                         into buf_host (NUL terminated); returns the number of bytes the
+ *                         full report needs (call again with a bigger buffer if > cap).
+ * ------------------------------------------------------------------------------------ */
+int vah_prof_enable(int on);
+int64_t vah_prof_report(char *buf_host, int64_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITADAPTER_HIP_H */

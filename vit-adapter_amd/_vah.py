@@ -1,0 +1,75 @@
+"""ctypes loader for libvitadapter_hip.so (the C ABI in include/vitadapter_hip.h).
+
+The library is the product: there is NO fallback.  If it has not been built
+(`python vit-adapter_amd/build.py`), importing this module raises ImportError.
+"""
+import ctypes
+import os
+
+# torch MUST be imported before the library is loaded: the PyTorch-ROCm wheel bundles its own
+# libamdhip64.so, and the kernels have to be registered with (and launched through) the same
+# HIP runtime instance that owns torch's streams and allocations.  Loading our library first
+# would pull in /opt/rocm's runtime as a second instance ("no ROCm-capable device" at launch).
+import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
+ABI_VERSION = 1
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        'libvitadapter_hip.so is missing (%s): build it with `python vit-adapter_amd/build.py` '
+        '(hipcc --offload-arch=gfx950).  There is no CPU or PyTorch fallback.' % LIB_PATH)
+
+lib = ctypes.CDLL(LIB_PATH)
+
+_i64 = ctypes.c_int64
+_p = ctypes.c_void_p
+
+lib.vah_abi_version.restype = ctypes.c_int
+lib.vah_last_error.restype = ctypes.c_char_p
+lib.vah_prof_enable.argtypes = [ctypes.c_int]
+lib.vah_prof_enable.restype = ctypes.c_int
+lib.vah_prof_report.argtypes = [ctypes.c_char_p, _i64]
+lib.vah_prof_report.restype = _i64
+for _sfx in ('f32', 'f64'):
+    _f = getattr(lib, 'vah_msda_forward_' + _sfx)
+    _f.argtypes = [_p] * 5 + [_i64] * 7 + [_p, _p]
+    _f.restype = ctypes.c_int
+    _b = getattr(lib, 'vah_msda_backward_' + _sfx)
+    _b.argtypes = [_p] * 6 + [_i64] * 7 + [_p] * 4
+    _b.restype = ctypes.c_int
+
+if lib.vah_abi_version() != ABI_VERSION:
+    raise ImportError('libvitadapter_hip.so ABI %d != binding ABI %d: rebuild the library'
+                      % (lib.vah_abi_version(), ABI_VERSION))
+
+# every symbol include/vitadapter_hip.h declares (checked by tests/test_capi_symbols.py)
+EXPORTS = (
+    'vah_abi_version', 'vah_last_error', 'vah_prof_enable', 'vah_prof_report',
+    'vah_msda_forward_f32', 'vah_msda_forward_f64',
+    'vah_msda_backward_f32', 'vah_msda_backward_f64',
+)
+
+
+def check(rc, what):
+    """Turn a non-zero ABI return code into RuntimeError (the reference only printf()s)."""
+    if rc != 0:
+        msg = lib.vah_last_error().decode('utf-8', 'replace')
+        raise RuntimeError('%s failed (code %d): %s' % (what, rc, msg))
+
+
+def prof_enable(on):
+    lib.vah_prof_enable(1 if on else 0)
+
+
+def prof_report():
+    """-> {kernel_name: dict(calls, total_ms, bytes)}; synchronises the recorded events."""
+    need = lib.vah_prof_report(None, 0)
+    buf = ctypes.create_string_buffer(int(need) + 64)
+    lib.vah_prof_report(buf, len(buf))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, calls, ms, nbytes = line.split()
+        out[name] = dict(calls=int(calls), total_ms=float(ms), bytes=int(nbytes))
+    return out
