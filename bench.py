@@ -1,0 +1,236 @@
+#!/usr/bin/env python
+"""bench.py -- ViT-Adapter-B 1024x1024 training step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One process per GPU; data parallel over RCCL (torch DDP, gradient all-reduce overlapped with
+backward, SyncBatchNorm statistics exchanged per layer).  A "step" is one full pass of the hot
+path over one synthetic batch: zero_grad -> ViTAdapter forward (bf16 autocast, deformable
+attention in fp32 on the HIP kernels) -> loss = sum_k mean(f_k) -> backward (+ gradient
+all-reduce) -> fused AdamW update.  Inputs are resident in HBM before the timed region.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  "roofline":     the MSDA kernel with the largest total time in the timed region: algorithmic
+                  bytes per launch / mean launch duration (HIP events recorded by the library on
+                  the launch stream during the timed steps) against the 8 TB/s HBM3E peak
+  "cpu_baseline": the oracle restatement of the same backbone (oracle/vit_adapter_ref.py, kind
+                  "port") run fwd+bwd on the host cores on a bounded sample (one image), plus the
+                  reference's pure-PyTorch MSDA core on BASELINE config 1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'vit-adapter_amd'))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK = 8.0e12     # B/s, MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--preset', default='base_det', help='vitadapter preset (base_det = BASELINE configs[2])')
+    ap.add_argument('--size', type=int, nargs=2, default=[1024, 1024], metavar=('H', 'W'))
+    ap.add_argument('--batch', type=int, default=2, help='per-GPU batch')
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'full', 'small', 'none'],
+                    help="auto: 'full' (one 1024^2 image) at N=1 on rank 0, none otherwise")
+    ap.add_argument('--no-optimizer', action='store_true', help='diagnostic only: skip AdamW')
+    return ap.parse_args()
+
+
+def host_cores():
+    """CPU share of this process: cgroup quota if set, else the affinity mask (never the raw
+    os.cpu_count() of a shared host, which oversubscribes the box and runs ~100x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("VAH_CPU_THREADS", "16"))))
+
+
+def cpu_baseline(args, preset_kw):
+    """Oracle (CPU port of the reference) on the host cores; bounded sample, same workload."""
+    from oracle import cases, msda as oracle_msda, seeded, vit_adapter_ref as ref
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    out = {'cores': cores, 'kind': 'port', 'unit': 'images/sec'}
+
+    # (a) the reference's pure-PyTorch MSDA core on BASELINE config 1 (north-star CPU leg)
+    N, M, D, P, Lq, shapes, _ = cases.bench_inputs('cfg1')
+    L, S = len(shapes), sum(h * w for h, w in shapes)
+    g = torch.Generator().manual_seed(0)
+    value = (torch.rand(N, S, M, D, generator=g) * 0.01).requires_grad_(True)
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=g).requires_grad_(True)
+    attn = torch.rand(N, Lq, M, L, P, generator=g) + 1e-5
+    attn = (attn / attn.sum((-1, -2), keepdim=True)).requires_grad_(True)
+    tf, tfb = [], []
+    for it in range(2 + 5):
+        t0 = time.perf_counter()
+        o = oracle_msda.core_torch(value, shapes, loc, attn)
+        t1 = time.perf_counter()
+        o.sum().backward()
+        t2 = time.perf_counter()
+        if it >= 2:
+            tf.append(t1 - t0)
+            tfb.append(t2 - t0)
+    fb = 4 * (N * S * M * D + 3 * N * Lq * M * L * P + N * Lq * M * D)
+    out['msda_core_cfg1'] = {'fwd_ms': round(1e3 * sorted(tf)[len(tf) // 2], 2),
+                             'fwd_bwd_ms': round(1e3 * sorted(tfb)[len(tfb) // 2], 2),
+                             'fwd_GBps': round(fb / sorted(tf)[len(tf) // 2] / 1e9, 3)}
+
+    # (b) the whole backbone step on one image
+    mode = args.cpu_baseline
+    H, W = args.size if mode == 'full' else (256, 256)
+    from vitadapter.backbones import ViTAdapter
+    kw = dict(preset_kw)
+    shapes_sd = {k: tuple(v.shape) for k, v in ViTAdapter(**kw).state_dict().items()}
+    sd = seeded.seeded_state_dict(shapes_sd, 0)
+    for k, v in sd.items():
+        if v.is_floating_point() and 'running_' not in k:
+            v.requires_grad_(True)
+    cfg = ref.Cfg(**kw)
+    x = torch.randn(1, 3, H, W, generator=g)
+    t0 = time.perf_counter()
+    outs = ref.vit_adapter_forward(sd, x, cfg, training=True)
+    sum(o.mean() for o in outs).backward()
+    dt = time.perf_counter() - t0
+    out['value'] = round(1.0 / dt, 4)
+    out['sample'] = ('oracle ViT-Adapter (%s) fwd+bwd, fp32, 1 image %dx%d, 1 pass, %.1f s'
+                     % (args.preset, H, W, dt))
+    if (H, W) != tuple(args.size):
+        out['sample'] += ' (reduced size: not the bench workload)'
+    return out
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=dev)
+
+    import _vah
+    from vitadapter.backbones.vit_adapter import PRESETS, ViTAdapter
+
+    preset_kw = dict(PRESETS[args.preset])
+    torch.manual_seed(0)
+    model = ViTAdapter(**preset_kw).to(dev).train()
+    n_params = sum(p.numel() for p in model.parameters())
+    net = model
+    if world > 1:
+        net = torch.nn.parallel.DistributedDataParallel(
+            model, device_ids=[local_rank], bucket_cap_mb=64, gradient_as_bucket_view=True,
+            broadcast_buffers=False)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.05, fused=True)
+    amp = torch.bfloat16 if args.dtype == 'bf16' else None
+
+    H, W = args.size
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    x = torch.randn(args.batch, 3, H, W, device=dev, generator=gen)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=amp, enabled=amp is not None):
+            feats = net(x)
+        loss = sum(f.float().mean() for f in feats)
+        loss.backward()
+        if not args.no_optimizer:
+            opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    _vah.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    _vah.prof_enable(False)
+    prof = _vah.prof_report()
+    assert torch.isfinite(loss).item(), 'loss is not finite'
+
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    if rank == 0:
+        ips = world * args.batch * args.steps / dt
+        kernels = {}
+        for name, r in prof.items():
+            if r['calls'] == 0:
+                continue
+            avg_s = r['total_ms'] * 1e-3 / r['calls']
+            per_launch = r['bytes'] / r['calls']
+            kernels[name] = {'calls_per_step': r['calls'] / args.steps, 'avg_us': round(avg_s * 1e6, 2),
+                             'bytes_per_launch': int(per_launch),
+                             'achieved_GBps': round(per_launch / avg_s / 1e9, 1),
+                             'frac_of_hbm_peak': round(per_launch / avg_s / HBM_PEAK, 4),
+                             'ms_per_step': round(r['total_ms'] / args.steps, 3)}
+        msda = {k: v for k, v in kernels.items() if k.startswith('msda_')}
+        roofline = None
+        if msda:
+            dom = max(msda, key=lambda k: msda[k]['ms_per_step'])
+            a = msda[dom]['achieved_GBps']
+            roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK / 1e9,
+                        'unit': 'GB/s', 'frac': round(a / (HBM_PEAK / 1e9), 4), 'traffic': None,
+                        'avg_launch_us': msda[dom]['avg_us'],
+                        'algorithmic_bytes_per_launch': msda[dom]['bytes_per_launch']}
+        line = {
+            'metric': 'images/sec ViT-Adapter-B 1024x1024 fwd+bwd (+AdamW step)',
+            'value': round(ips, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'ViT-Adapter-%s (%s) %dx%d, per-GPU batch %d, train mode, '
+                                   'drop_path %.1f, SyncBN, %s' % (
+                                       args.preset, preset_kw['flavour'], H, W, args.batch,
+                                       preset_kw['drop_path_rate'],
+                                       'step = fwd+bwd' if args.no_optimizer else 'step = fwd+bwd+AdamW'),
+                       'global_batch': world * args.batch, 'params_M': round(n_params / 1e6, 2),
+                       'parallelism': 'dp%d' % world},
+            'roofline': roofline,
+            'kernels': kernels,
+        }
+        mode = args.cpu_baseline
+        if mode == 'auto':
+            mode = 'full' if world == 1 else 'none'
+        if mode != 'none':
+            args.cpu_baseline = mode
+            line['cpu_baseline'] = cpu_baseline(args, preset_kw)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

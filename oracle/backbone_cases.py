@@ -1,0 +1,80 @@
+"""oracle/backbone_cases.py -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Config literals + seeded inputs of the backbone goldens, shared by tools/gen_golden_backbone.py
+(feeds the reference's classes) and the tests (feed the oracle restatement and the HIP-backed
+product modules).  Small on purpose; D = 32 per deformable head as in every reference config.
+"""
+import torch
+
+from . import cases, seeded
+
+_SMALL = dict(patch_size=16, embed_dim=64, depth=4, num_heads=1, mlp_ratio=4, drop_path_rate=0.,
+              conv_inplane=16, n_points=4, deform_num_heads=2, cffn_ratio=0.25, deform_ratio=1.0,
+              interaction_indexes=[[0, 0], [1, 1], [2, 2], [3, 3]])
+
+FULL_CASES = {
+    # seg flavour, all-global attention (configs[1] family), square input
+    'seg_glob_64': dict(cfg=dict(flavour='seg', window_attn=[False] * 4, window_size=[None] * 4,
+                                 **_SMALL), hw=(64, 64), batch=2, modes=('eval', 'train')),
+    # det flavour, window/global mix (configs[2] family), non-square input -> padded windows
+    'det_win_96x128': dict(cfg=dict(flavour='det', window_attn=[True, False, True, False],
+                                    window_size=[14, None, 14, None],
+                                    **dict(_SMALL, deform_ratio=0.5, deform_num_heads=1)),
+                           hw=(96, 128), batch=1, modes=('eval', 'train')),
+    # det flavour with windows, no extra extractors, no ConvFFN, 2 blocks per interaction, only 2
+    # interactions (the seg forward needs exactly 4: S/vit_adapter.py:126 unpacks four stage maps)
+    'det_win_64x96': dict(cfg=dict(flavour='det', window_attn=[True, True, False, False],
+                                   window_size=[14, 14, None, None], use_extra_extractor=False,
+                                   with_cffn=False,
+                                   **dict(_SMALL, interaction_indexes=[[0, 1], [2, 3]])),
+                          hw=(64, 96), batch=2, modes=('eval',)),
+}
+
+
+def full_input(name):
+    c = FULL_CASES[name]
+    return seeded.randn('full/%s/x' % name, (c['batch'], 3) + tuple(c['hw']), 11)
+
+
+def full_gouts(name, shapes):
+    return [seeded.randn('full/%s/g%d' % (name, k), s, 11) for k, s in enumerate(shapes)]
+
+
+PART = dict(embed=64, deform_heads=2, ratio=1.0, heads=1, tokens=4, inplanes=16, batch=2)
+
+
+def part_geometry():
+    """(injector geometry, extractor geometry) for a 64x64 image: [ref points, shapes, lsi]."""
+    t = PART['tokens']
+    pyramid = [(2 * t, 2 * t), (t, t), (t // 2, t // 2)]
+    vit = [(t, t)]
+    out = []
+    for vshapes, qshapes in ((pyramid, vit), (vit, pyramid)):
+        out.append([cases.reference_grid(qshapes), torch.as_tensor(vshapes, dtype=torch.long),
+                    cases.level_start_index(vshapes)])
+    return out
+
+
+def part_tokens():
+    t, E, B = PART['tokens'], PART['embed'], PART['batch']
+    x = seeded.randn('part/x', (B, t * t, E), 12)
+    c = seeded.randn('part/c', (B, 21 * (t // 2) ** 2, E), 12)
+    return x, c
+
+
+def part_image():
+    t = PART['tokens']
+    return seeded.randn('part/img', (PART['batch'], 3, 16 * t, 16 * t), 12)
+
+
+def part_gout(tag, shape):
+    return seeded.randn('part/g/' + tag, tuple(shape), 12)
+
+
+# name: (windowed, H, W) token grids; window 14 -> 10x17 pads to 14x28 (two windows)
+BLOCK_CASES = {'blk_global': (False, 6, 7), 'blk_window': (True, 10, 17), 'blk_window_exact': (True, 14, 14)}
+
+
+def block_tokens(name):
+    _, H, W = BLOCK_CASES[name]
+    return seeded.randn('part/blk/' + name, (PART['batch'], H * W, PART['embed']), 12)

@@ -1,0 +1,188 @@
+"""GPU: the HIP-backed product modules (MSDeformAttn, Injector, Extractor, SPM, Block,
+ViTAdapter seg/det) against the reference goldens (tests/golden/msda_module.npz,
+backbone.npz), with seeded weights/inputs regenerated from oracle/seeded.py.
+
+Tolerance: fp32 end to end; 1e-4 relative for single modules, 1e-3 for the 4-block backbone
+(SURVEY.md section 8d parity gate: accumulated fp32 rounding through attention + BN)."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import backbone_cases as bc
+from oracle import cases, seeded
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _fp32_math():
+    torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
+    yield
+
+
+def _close(got, want, tol, what):
+    got = got.detach().double().cpu().numpy() if torch.is_tensor(got) else got
+    want = want.astype(np.float64)
+    assert got.shape == want.shape, what
+    err = np.abs(got - want).max()
+    assert np.isfinite(got).all(), what
+    assert err <= tol * max(1.0, np.abs(want).max()), '%s: %.3e (ref max %.3e)' % (what, err, np.abs(want).max())
+
+
+def _close_but_for_pool_flips(got, want, tol, what, max_outliers=0.02):
+    """d(loss)/d(image) runs backwards through the stem's 3x3 max-pool.  GPU and CPU convolutions
+    differ by ~1e-6 in the activations, which flips the arg-max of near-tied pool windows and
+    re-routes the gradient of those windows to a neighbouring pixel (measured: up to ~1% of pixels,
+    tools/debug/dbg_spm2.py).  The function is non-smooth there, so a handful of outliers is
+    tolerated; everything else must meet ``tol`` and the relative L2 error stays small."""
+    got = got.detach().double().cpu().numpy()
+    want = want.astype(np.float64)
+    assert got.shape == want.shape and np.isfinite(got).all(), what
+    err = np.abs(got - want)
+    bound = tol * max(1.0, np.abs(want).max())
+    frac = float((err > bound).mean())
+    rel_l2 = float(np.sqrt((err ** 2).sum() / (want ** 2).sum()))
+    assert frac <= max_outliers and rel_l2 <= 0.05, '%s: %.4f of elements off, rel L2 %.3e' % (what, frac, rel_l2)
+
+
+def _seed_module(m, seed):
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict(seeded.seeded_state_dict(shapes, seed))
+    return m.cuda()
+
+
+# module cases of tools/gen_golden.py (kept in sync by name)
+MODULE_CASES = {
+    'inj_t': (192, 3, 6, 4, 1.0, 16, [(8, 8), (4, 4), (2, 2)], [(4, 4)], 2),
+    'ext_t': (192, 1, 6, 4, 1.0, 84, [(4, 4)], [(8, 8), (4, 4), (2, 2)], 2),
+    'inj_b': (768, 3, 12, 4, 0.5, 16, [(8, 8), (4, 4), (2, 2)], [(4, 4)], 1),
+    'ext_b': (768, 1, 12, 4, 0.5, 84, [(4, 4)], [(8, 8), (4, 4), (2, 2)], 1),
+}
+
+
+@pytest.mark.parametrize('name', sorted(MODULE_CASES))
+def test_msdeformattn_module_matches_reference(golden_dir, name):
+    from ops.modules import MSDeformAttn
+    gold = np.load(os.path.join(golden_dir, 'msda_module.npz'))
+    d_model, L, M, P, ratio, Lq, vshapes, qshapes, N = MODULE_CASES[name]
+    m = MSDeformAttn(d_model=d_model, n_levels=L, n_heads=M, n_points=P, ratio=ratio)
+    meta = json.loads(str(gold['meta']))[name]
+    assert {k: list(v.shape) for k, v in m.state_dict().items()} == meta
+    m = _seed_module(m, 2)
+    S = sum(h * w for h, w in vshapes)
+    query = seeded.randn('module/%s/query' % name, (N, Lq, d_model), 1).cuda().requires_grad_(True)
+    feat = seeded.randn('module/%s/feat' % name, (N, S, d_model), 1).cuda().requires_grad_(True)
+    ref = cases.reference_grid(qshapes).cuda()
+    hw = torch.as_tensor(vshapes, dtype=torch.long).cuda()
+    lsi = cases.level_start_index(vshapes).cuda()
+    gout = seeded.randn('module/%s/gout' % name, (N, Lq, d_model), 1).cuda()
+    out = m(query, ref, feat, hw, lsi, None)
+    out.backward(gout)
+    _close(out, gold[name + '_out'], 1e-4, 'out')
+    _close(query.grad, gold[name + '_gquery'], 1e-4, 'grad query')
+    _close(feat.grad, gold[name + '_gfeat'], 1e-4, 'grad feat')
+    for k, p in m.named_parameters():
+        want = gold['%s_gparam_%s' % (name, k)]
+        got = seeded.digest(p.grad)
+        assert np.abs(got - want).max() <= 2e-4 * max(1.0, np.abs(want).max()), k
+
+
+def test_parts_match_reference(golden_dir):
+    from vitadapter.backbones import adapter_modules as am
+    from vitadapter.backbones import vit
+    gold = np.load(os.path.join(golden_dir, 'backbone.npz'))
+    E, M, R = bc.PART['embed'], bc.PART['deform_heads'], bc.PART['ratio']
+    H = W = bc.PART['tokens']
+    geo1, geo2 = [[t.cuda() for t in g] for g in bc.part_geometry()]
+    x, c = [t.cuda() for t in bc.part_tokens()]
+
+    inj = _seed_module(am.Injector(dim=E, n_levels=3, num_heads=M, n_points=4, deform_ratio=R), 6)
+    xi, ci = x.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    o = inj(xi, geo1[0], ci, geo1[1], geo1[2])
+    g = torch.autograd.grad((o * bc.part_gout('inj', o.shape).cuda()).sum(), [xi, ci])
+    _close(o, gold['part_inj_out'], 1e-4, 'inj out')
+    _close(g[0], gold['part_inj_gx'], 1e-4, 'inj gx')
+    _close(g[1], gold['part_inj_gc'], 1e-4, 'inj gc')
+
+    ext = _seed_module(am.Extractor(dim=E, num_heads=M, n_points=4, n_levels=1, deform_ratio=R), 7)
+    xi, ci = x.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    o = ext(ci, geo2[0], xi, geo2[1], geo2[2], H, W)
+    g = torch.autograd.grad((o * bc.part_gout('ext', o.shape).cuda()).sum(), [xi, ci])
+    _close(o, gold['part_ext_out'], 1e-4, 'ext out')
+    _close(g[0], gold['part_ext_gx'], 1e-4, 'ext gx')
+    _close(g[1], gold['part_ext_gc'], 1e-4, 'ext gc')
+
+    spm = _seed_module(am.SpatialPriorModule(inplanes=bc.PART['inplanes'], embed_dim=E), 8)
+    for mode in ('eval', 'train'):
+        spm.train(mode == 'train')
+        img = bc.part_image().cuda().requires_grad_(True)
+        outs = spm(img)
+        g = torch.autograd.grad(sum((o * bc.part_gout('spm%d' % k, o.shape).cuda()).sum()
+                                    for k, o in enumerate(outs)), [img])
+        for k, o in enumerate(outs):
+            _close(o, gold['part_spm_%s_c%d' % (mode, k + 1)], 1e-4, 'spm c%d' % (k + 1))
+        _close_but_for_pool_flips(g[0], gold['part_spm_%s_gimg' % mode], 2e-4, 'spm gimg')
+
+    for bname, (windowed, Hb, Wb) in bc.BLOCK_CASES.items():
+        blk = _seed_module(vit.Block(dim=E, num_heads=bc.PART['heads'], mlp_ratio=4., qkv_bias=True,
+                                     windowed=windowed, window_size=14, layer_scale=True), 9)
+        t = bc.block_tokens(bname).cuda().requires_grad_(True)
+        o = blk(t, Hb, Wb)
+        g = torch.autograd.grad((o * bc.part_gout(bname, o.shape).cuda()).sum(), [t])
+        _close(o, gold['part_%s_out' % bname], 1e-4, bname)
+        _close(g[0], gold['part_%s_gx' % bname], 1e-4, bname + ' gx')
+
+
+@pytest.mark.parametrize('name', sorted(bc.FULL_CASES))
+def test_vit_adapter_matches_reference(golden_dir, name):
+    from vitadapter.backbones import ViTAdapter
+    gold = np.load(os.path.join(golden_dir, 'backbone.npz'))
+    case = bc.FULL_CASES[name]
+    model = _seed_module(ViTAdapter(**case['cfg']), 5)
+    H, W = case['hw']
+    for mode in case['modes']:
+        model.train(mode == 'train')
+        model.zero_grad(set_to_none=True)
+        x = bc.full_input(name).cuda().requires_grad_(True)
+        outs = model(x)
+        assert [tuple(o.shape) for o in outs] == [
+            (case['batch'], case['cfg']['embed_dim'], H // s, W // s) for s in (4, 8, 16, 32)]
+        tag = '%s_%s' % (name, mode)
+        for k, o in enumerate(outs):
+            _close(o, gold['%s_f%d' % (tag, k + 1)], 1e-3, '%s f%d' % (tag, k + 1))
+        gouts = [g.cuda() for g in bc.full_gouts(name, [o.shape for o in outs])]
+        sum((o * g).sum() for o, g in zip(outs, gouts)).backward()
+        _close_but_for_pool_flips(x.grad, gold[tag + '_gx'], 1e-3, tag + ' grad x')
+        checked = 0
+        for k, p in model.named_parameters():
+            key = '%s_gp_%s' % (tag, k)
+            if key in gold.files and p.grad is not None:
+                want = gold[key]
+                got = seeded.digest(p.grad)
+                # the three stem convs / norms sit below the max-pool (see _close_but_for_pool_flips)
+                tol = 5e-2 if k.startswith('spm.stem') else 2e-3
+                assert np.abs(got - want).max() <= tol * max(1.0, np.abs(want).max()), key
+                checked += 1
+        assert checked > 100
+
+
+def test_full_size_pyramid_shapes_and_finiteness():
+    """configs[1]: ViT-Adapter-T 512x512 batch 2 fwd+bwd on random tensors (reference init)."""
+    from vitadapter.backbones.vit_adapter import build_preset
+    torch.manual_seed(0)
+    model = build_preset('tiny_seg').cuda().train()
+    x = torch.randn(2, 3, 512, 512, device='cuda')
+    outs = model(x)
+    assert [tuple(o.shape) for o in outs] == [(2, 192, 128, 128), (2, 192, 64, 64),
+                                              (2, 192, 32, 32), (2, 192, 16, 16)]
+    sum(o.float().mean() for o in outs).backward()
+    assert all(torch.isfinite(o).all() for o in outs)
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    assert len(grads) > 300 and all(torch.isfinite(g).all() for g in grads)

@@ -1,0 +1,3 @@
+from .vit_adapter import ViTAdapter, ViTAdapterDet, ViTAdapterSeg, register_backbones
+
+__all__ = ['ViTAdapter', 'ViTAdapterSeg', 'ViTAdapterDet', 'register_backbones']
