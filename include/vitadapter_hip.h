@@ -91,6 +91,42 @@ int vah_msda_backward_f64(const double *value, const int64_t *shapes, const int6
                           double *grad_value, double *grad_loc, double *grad_attn, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Windowed variants (fp32, D == 32, L <= 4): same tensors, same results up to fp32 summation
+ * order, plus a QUERY SCHEDULE that lets one workgroup keep the value rows (and in the backward
+ * the grad_value rows) of a spatially compact group of queries in LDS.
+ *
+ *   perm       (Lq,)          int32  a permutation of [0, Lq): the queries, group by group
+ *   group_off  (n_groups+1,)  int32  group g owns perm[group_off[g] .. group_off[g+1])
+ *   max_group                        size of the largest group (its sampling locations and
+ *                                    weights, 12 bytes per sample, are kept in LDS too)
+ *   budget_px                        LDS window capacity in 128-byte pixel rows; forward uses
+ *                                    budget_px*128 B of LDS per workgroup; backward the same for
+ *                                    its grad_value windows and, when stage != 0, as much
+ *                                    again for value windows (total must stay below 160 KiB;
+ *                                    with stage == 0 value corners are read from global)
+ * The schedule is a performance hint only: any permutation / grouping gives the same result
+ * (samples that miss the LDS windows take the plain global path).  `perm` MUST be a permutation
+ * (a repeated query would be accumulated twice into grad_value); out-of-range entries are
+ * skipped.  The reference has no counterpart: its kernels take one thread per output scalar
+ * (ms_deform_im2col_cuda.cuh:237-299) and one global atomic per sample, corner and channel
+ * (:87-159).  The schedule is shared by all batch elements.
+ * ------------------------------------------------------------------------------------ */
+int vah_msda_forward_win_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                             const float *loc, const float *attn,
+                             const int32_t *group_off, const int32_t *perm,
+                             int64_t n_groups, int64_t max_group, int64_t budget_px,
+                             int64_t N, int64_t S, int64_t M, int64_t D,
+                             int64_t L, int64_t Lq, int64_t P,
+                             float *out, void *stream);
+int vah_msda_backward_win_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                              const float *loc, const float *attn, const float *grad_out,
+                              const int32_t *group_off, const int32_t *perm,
+                              int64_t n_groups, int64_t max_group, int64_t budget_px, int stage,
+                              int64_t N, int64_t S, int64_t M, int64_t D,
+                              int64_t L, int64_t Lq, int64_t P,
+                              float *grad_value, float *grad_loc, float *grad_attn, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Launch timing (bench.py's roofline leg).  While enabled, every kernel launched through
  * this library is bracketed by two hipEvents recorded on the launch's own stream.
  *   vah_prof_enable(1)  : start collecting (drops anything collected before)

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
-ABI_VERSION = 1
+ABI_VERSION = 3
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -40,6 +40,11 @@ for _sfx in ('f32', 'f64'):
     _b.argtypes = [_p] * 6 + [_i64] * 7 + [_p] * 4
     _b.restype = ctypes.c_int
 
+lib.vah_msda_forward_win_f32.argtypes = [_p] * 7 + [_i64] * 10 + [_p, _p]
+lib.vah_msda_forward_win_f32.restype = ctypes.c_int
+lib.vah_msda_backward_win_f32.argtypes = [_p] * 8 + [_i64, _i64, _i64, ctypes.c_int] + [_i64] * 7 + [_p] * 4
+lib.vah_msda_backward_win_f32.restype = ctypes.c_int
+
 if lib.vah_abi_version() != ABI_VERSION:
     raise ImportError('libvitadapter_hip.so ABI %d != binding ABI %d: rebuild the library'
                       % (lib.vah_abi_version(), ABI_VERSION))
@@ -49,6 +54,7 @@ EXPORTS = (
     'vah_abi_version', 'vah_last_error', 'vah_prof_enable', 'vah_prof_report',
     'vah_msda_forward_f32', 'vah_msda_forward_f64',
     'vah_msda_backward_f32', 'vah_msda_backward_f64',
+    'vah_msda_forward_win_f32', 'vah_msda_backward_win_f32',
 )
 
 

@@ -29,4 +29,30 @@ int check_launch(const char *what);
 constexpr int kCUs = 256;   // MI355X: 8 XCDs x 32 CUs
 constexpr int kWave = 64;
 
+#if defined(__HIPCC__)
+// Cross-lane adds on the VALU (DPP) instead of ds_bpermute: __shfl_xor lowers to an LDS-pipeline
+// instruction on gfx950, which competes with the LDS atomics / reads of the gather kernels.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL,
+                                                                 ROW_MASK, 0xF, false));
+}
+
+// Sum over each aligned group of 16 lanes; every lane of the group ends up with the sum.
+__device__ __forceinline__ float dpp_sum16(float x) {
+    x += dpp_mov<0xB1, 0xF>(x);     // quad_perm [1,0,3,2]
+    x += dpp_mov<0x4E, 0xF>(x);     // quad_perm [2,3,0,1]
+    x += dpp_mov<0x141, 0xF>(x);    // row_half_mirror
+    x += dpp_mov<0x140, 0xF>(x);    // row_mirror
+    return x;
+}
+
+// Sum over each aligned group of 32 lanes.  The result is valid in the UPPER 16 lanes of the
+// group (lanes 16..31 and 48..63): row_bcast15 hands row 0's total to row 1 and row 2's to row 3.
+__device__ __forceinline__ float dpp_sum32_hi(float x) {
+    x = dpp_sum16(x);
+    return x + dpp_mov<0x142, 0xA>(x);
+}
+#endif
+
 }  // namespace vah

@@ -163,12 +163,17 @@ __global__ __launch_bounds__(kBlock) void msda_fwd_vec4(
 // ---------------------------------------------------------------------------------------
 // Backward, f32, one lane per channel, D in {16, 32, 64}.
 // ---------------------------------------------------------------------------------------
+// Sum over the D lanes of a row.  kResultLane<D> is the lane (within the row) that holds it.
 template <int D>
 __device__ __forceinline__ float group_sum(float x) {
+    if constexpr (D == 32) return dpp_sum32_hi(x);
+    if constexpr (D == 16) return dpp_sum16(x);
 #pragma unroll
     for (int o = D / 2; o >= 1; o >>= 1) x += __shfl_xor(x, o, 64);
     return x;
 }
+template <int D>
+constexpr int kResultLane = (D == 32) ? 16 : 0;
 
 template <int D, int PU>
 __global__ __launch_bounds__(kBlock) void msda_bwd_lanec(
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_lanec(
                 const float pa = group_sum<D>(g * val);
                 const float pw = group_sum<D>((float)lv.W * gw * tv);
                 const float ph = group_sum<D>((float)lv.H * gh * tv);
-                if (c == 0) {
+                if (c == kResultLane<D>) {
                     *reinterpret_cast<float2 *>(glp + 2 * s) = make_float2(pw, ph);
                     gap[s] = pa;
                 }
