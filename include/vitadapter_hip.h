@@ -127,6 +127,38 @@ int vah_msda_backward_win_f32(const float *value, const int64_t *shapes, const i
                               float *grad_value, float *grad_loc, float *grad_attn, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Softmax attention of the ViT blocks, bf16, head_dim 64  
+ *
+ * Replaces the score / softmax / value products of the reference's Attention and
+ * WindowedAttention (/root/reference/detection/mmdet_custom/models/backbones/base/vit.py:83-88
+ * and :154-159): out = softmax(q k^T * scale) v per (batch, head), no mask, no dropout.  The
+ * N x N score matrix is never materialised.
+ *
+ *   q, k, v  bf16, read in place from the fused projection: element (b, n, h, d) of each lives at
+ *            ptr[b*batch_stride + n*ld + h*64 + d]   (ld = 3*heads*64 for a packed qkv buffer)
+ *   out      bf16 (B, N, heads, 64) with row stride ld_out elements
+ *   lse      fp32 (B, heads, N): log2-domain log-sum-exp of the scaled scores (kept for backward)
+ *   vt_ws    bf16 workspace of B*heads*64*vah_attn_padded_len(N) elements (V transposed)
+ * ------------------------------------------------------------------------------------ */
+int64_t vah_attn_padded_len(int64_t N);
+int vah_attn_fwd_bf16(const void *q, const void *k, const void *v, int64_t ld, int64_t batch_stride,
+                      int64_t B, int64_t H, int64_t N, float scale, void *vt_ws,
+                      void *out, int64_t ld_out, float *lse, void *stream);
+
+/* Backward of the same op (the reference differentiates the materialised softmax with autograd;
+ * here the probabilities are recomputed from q, k and lse).  dq / dk / dv are bf16 and use the
+ * addressing of q / k / v with (ld_d, batch_stride_d): pass the three slices of one packed
+ * (B, N, 3, heads, 64) buffer to get the gradient of the fused qkv projection output directly.
+ * ws: vah_attn_bwd_workspace_bytes(B, H, N) bytes, 16-byte aligned.  No atomics: results are
+ * bitwise reproducible. */
+int64_t vah_attn_bwd_workspace_bytes(int64_t B, int64_t H, int64_t N);
+int vah_attn_bwd_bf16(const void *q, const void *k, const void *v, int64_t ld, int64_t batch_stride,
+                      const void *out, const void *dout, int64_t ld_out, const float *lse,
+                      int64_t B, int64_t H, int64_t N, float scale, void *ws,
+                      void *dq, void *dk, void *dv, int64_t ld_d, int64_t batch_stride_d,
+                      void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Launch timing (bench.py's roofline leg).  While enabled, every kernel launched through
  * this library is bracketed by two hipEvents recorded on the launch's own stream.
  *   vah_prof_enable(1)  : start collecting (drops anything collected before)

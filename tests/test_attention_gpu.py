@@ -1,0 +1,62 @@
+"""GPU: bf16 MFMA attention (csrc/attn_*.hip) against an fp32 PyTorch statement of the
+reference's Attention arithmetic (detection/mmdet_custom/models/backbones/base/vit.py:83-88):
+softmax(q k^T * scale) v.  Tolerance is bf16's: inputs and outputs carry 8 significant bits."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(qkv, scale):
+    q, k, v = qkv.float().permute(2, 0, 3, 1, 4).unbind(0)
+    a = ((q @ k.transpose(-2, -1)) * scale).softmax(-1)
+    return (a @ v).transpose(1, 2)
+
+
+@pytest.mark.parametrize('B,N,H', [(1, 64, 1), (2, 196, 3), (1, 128, 2), (2, 333, 2), (1, 1024, 4),
+                                   (3, 1, 1), (1, 65, 1), (2, 4096, 2)])
+def test_attention_forward_backward(B, N, H):
+    from vitadapter import kernels
+    torch.manual_seed(N + H)
+    qkv = (torch.randn(B, N, 3, H, 64, device='cuda') * 1.5).to(torch.bfloat16).requires_grad_(True)
+    scale = 64 ** -0.5
+    out = kernels.attention(qkv, scale)
+    assert out.dtype == torch.bfloat16 and out.shape == (B, N, H, 64)
+    qr = qkv.detach().clone().requires_grad_(True)
+    ref = _ref(qr, scale)
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 3e-2 * max(1.0, ref.abs().max().item()), err
+    g = torch.randn_like(ref)
+    out.backward(g.to(torch.bfloat16))
+    ref.backward(g)
+    gerr = (qkv.grad.float() - qr.grad.float()).abs().max().item()
+    assert gerr <= 6e-2 * max(1.0, qr.grad.float().abs().max().item()), gerr
+
+
+def test_attention_identity_structure():
+    """Exact-data check of the fragment maps: with one-hot probabilities the output must pick
+    the right value row, for asymmetric V (catches transposed / permuted k orders)."""
+    from vitadapter import kernels
+    B, N, H = 1, 200, 2
+    q = torch.zeros(B, N, H, 64, device='cuda')
+    k = torch.zeros(B, N, H, 64, device='cuda')
+    idx = torch.arange(N, device='cuda')
+    tgt = (idx * 7 + 3) % N                       # query i attends (almost) only to key tgt[i]
+    code = torch.randn(N, 64, device='cuda').sign()
+    k[0, :, :, :] = code[:, None, :]
+    q[0, :, :, :] = code[tgt][:, None, :] * 4.0    # dot = 256 for the target, ~0 otherwise
+    v = torch.arange(N * 64, device='cuda', dtype=torch.float32).view(N, 64) % 251 - 125.0
+    v = v[None, :, None, :].expand(B, N, H, 64)
+    qkv = torch.stack((q, k, v), 2).to(torch.bfloat16)
+    out = kernels.attention(qkv, 1.0)
+    want = v[0, tgt][:, 0, :].to(torch.bfloat16).float()
+    assert (out[0, :, 0].float() - want).abs().max().item() <= 1.0      # bf16 of values up to 125
+    assert (out[0, :, 1].float() - want).abs().max().item() <= 1.0
+
+
+def test_fp32_and_other_head_dims_use_library_gemms():
+    from vitadapter import kernels
+    qkv = torch.randn(1, 50, 3, 2, 32, device='cuda')
+    out = kernels.attention(qkv, 32 ** -0.5)
+    assert out.dtype == torch.float32
+    assert (out - _ref(qkv, 32 ** -0.5)).abs().max().item() < 1e-4

@@ -274,15 +274,19 @@ def _schedules(MSDA, name, kw, Lq, dev):
     shapes = kw['shapes']
     if kw.get('query_shapes'):
         ref = cases.reference_grid(kw['query_shapes']).to(dev)
+        os.environ['VAH_MSDA_WIN'] = '1'           # the windowed path is opt-in
         out['tiles'] = MSDA.build_query_schedule(ref, shapes)
+        os.environ.pop('VAH_MSDA_WIN')
+        assert out['tiles'].bwd_px > 0
     g = torch.Generator().manual_seed(7)
     perm = torch.randperm(Lq, generator=g).to(torch.int32).to(dev)
-    # one big group, generous budget
-    out['one_group'] = MSDA.QuerySchedule(torch.arange(Lq, dtype=torch.int32, device=dev),
-                                          torch.tensor([0, Lq], dtype=torch.int32, device=dev),
-                                          1, 300, 150, True)
+    # identity order in chunks of 96 queries, generous budget
+    cuts = list(range(0, Lq, 96)) + [Lq]
+    out['chunks'] = MSDA.QuerySchedule(torch.arange(Lq, dtype=torch.int32, device=dev),
+                                       torch.tensor(cuts, dtype=torch.int32, device=dev),
+                                       len(cuts) - 1, 300, 150, True)
     # random permutation, ragged groups (incl. empty ones), tiny budget -> mostly the fallback path
-    cuts = sorted(set([0, Lq] + torch.randint(0, Lq + 1, (5,), generator=g).tolist()))
+    cuts = sorted(set(list(range(0, Lq, 150)) + [Lq] + torch.randint(0, Lq + 1, (5,), generator=g).tolist()))
     cuts = [0, 0] + cuts[1:]                                   # an empty first group
     out['ragged_tiny'] = MSDA.QuerySchedule(perm, torch.tensor(cuts, dtype=torch.int32, device=dev),
                                             len(cuts) - 1, 9, 7, False)
@@ -316,7 +320,10 @@ def test_windowed_full_size_equals_plain(MSDA, cfg, mode):
     plain kernels' results (fp32 summation order aside) and keeps the adjoint identities."""
     v, s, i, l, a, g = _full_inputs(cfg, mode)
     N, M, D, P, Lq, shapes, qshapes = cases.bench_inputs(cfg)
+    os.environ['VAH_MSDA_WIN'] = '1'
     sched = MSDA.build_query_schedule(cases.reference_grid(qshapes).cuda(), shapes)
+    os.environ.pop('VAH_MSDA_WIN')
+    assert sched.bwd_px > 0
     assert sched.Lq == Lq and int(sched.group_off[-1]) == Lq
     assert torch.equal(torch.sort(sched.perm.long())[0], torch.arange(Lq, device='cuda'))
     out0 = MSDA.ms_deform_attn_forward(v, s, i, l, a, 64)
@@ -335,7 +342,9 @@ def test_function_uses_schedule_from_context(MSDA, Function):
     kw = cases.PARITY_CASES['ext256_b']
     value, hw, lsi, loc, attn, gout = cases.msda_inputs('ext256_b', **kw)
     v, s, i, l, a, g = _dev((value, hw, lsi, loc, attn, gout))
+    os.environ['VAH_MSDA_WIN'] = '1'
     sched = MSDA.build_query_schedule(cases.reference_grid(kw['query_shapes']).cuda(), kw['shapes'])
+    os.environ.pop('VAH_MSDA_WIN')
     v1 = v.clone().requires_grad_(True)
     with MSDA.query_schedule(sched):
         out = Function.apply(v1, s, i, l, a, 64)

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 5
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -45,6 +45,17 @@ lib.vah_msda_forward_win_f32.restype = ctypes.c_int
 lib.vah_msda_backward_win_f32.argtypes = [_p] * 8 + [_i64, _i64, _i64, ctypes.c_int] + [_i64] * 7 + [_p] * 4
 lib.vah_msda_backward_win_f32.restype = ctypes.c_int
 
+lib.vah_attn_padded_len.argtypes = [_i64]
+lib.vah_attn_padded_len.restype = _i64
+lib.vah_attn_fwd_bf16.argtypes = [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, ctypes.c_float, _p, _p, _i64, _p, _p]
+lib.vah_attn_fwd_bf16.restype = ctypes.c_int
+
+lib.vah_attn_bwd_workspace_bytes.argtypes = [_i64, _i64, _i64]
+lib.vah_attn_bwd_workspace_bytes.restype = _i64
+lib.vah_attn_bwd_bf16.argtypes = ([_p, _p, _p, _i64, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, ctypes.c_float]
+                                  + [_p] * 4 + [_i64, _i64, _p])
+lib.vah_attn_bwd_bf16.restype = ctypes.c_int
+
 if lib.vah_abi_version() != ABI_VERSION:
     raise ImportError('libvitadapter_hip.so ABI %d != binding ABI %d: rebuild the library'
                       % (lib.vah_abi_version(), ABI_VERSION))
@@ -55,6 +66,7 @@ EXPORTS = (
     'vah_msda_forward_f32', 'vah_msda_forward_f64',
     'vah_msda_backward_f32', 'vah_msda_backward_f64',
     'vah_msda_forward_win_f32', 'vah_msda_backward_win_f32',
+    'vah_attn_padded_len', 'vah_attn_fwd_bf16', 'vah_attn_bwd_workspace_bytes', 'vah_attn_bwd_bf16',
 )
 
 

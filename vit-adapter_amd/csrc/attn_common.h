@@ -1,0 +1,90 @@
+// Shared pieces of the bf16 MFMA attention kernels (gfx950, head_dim 64).
+//
+// All kernels use v_mfma_f32_32x32x16_bf16.  Lane l = (r = l & 31, h = l >> 5):
+//   A operand element j : A[row r][k = 8h + j]         (8 bf16)
+//   B operand element j : B[k = 8h + j][col r]         (8 bf16)
+//   C/D register i      : C[row (i&3) + 8(i>>2) + 4h][col r]
+// A 32x32 f32 accumulator X (rows on registers, column on the lane) can feed the next MFMA
+// without touching LDS when that product sums over X's ROW index: registers 8s..8s+7, converted
+// to bf16, are the k-step-s fragment, whose element j is X row 16s + 8(j>>2) + 4h + (j&3); the
+// OTHER operand's element j must then come from that same k (see krow()).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vah {
+namespace attn {
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+
+constexpr int kHD = 64;          // head dim
+constexpr int kPadRow = 72;      // LDS row stride (bf16) of a [rows][64] tile read with b128: 144 B
+constexpr int kPadT = 68;        // LDS row stride (bf16) of a [64 d][64 keys] transposed tile, b64 reads
+constexpr int kPadT32 = 36;      // LDS row stride (bf16) of a [64 d][32 queries] transposed tile
+
+__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// row of a C/D tile held in register i by lane half h
+__device__ __forceinline__ int crow(int i, int h) { return (i & 3) + 8 * (i >> 2) + 4 * h; }
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// registers 8s..8s+7 of an accumulator -> bf16 fragment of k-step s
+__device__ __forceinline__ bf16x8 pack_half(const f32x16 &x, int s) {
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (__bf16)x[8 * s + j];
+    return f;
+}
+
+// Fragment of a TRANSPOSED tile T[row = r][k] whose k order must match pack_half: elements 0..3
+// are k = 16s + 4h + 0..3 and elements 4..7 are k = 16s + 8 + 4h + 0..3 (two 8-byte reads).
+__device__ __forceinline__ bf16x8 load_kperm(const __bf16 *row_ptr, int s, int h) {
+    const bf16x4 lo = *reinterpret_cast<const bf16x4 *>(row_ptr + 16 * s + 4 * h);
+    const bf16x4 hi = *reinterpret_cast<const bf16x4 *>(row_ptr + 16 * s + 8 + 4 * h);
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f[j] = lo[j];
+        f[4 + j] = hi[j];
+    }
+    return f;
+}
+
+// (B, N, heads, 64) strided -> (B, heads, 64, Np) dense, zero padded beyond N.
+static __global__ __launch_bounds__(256) void transpose_to_dn(const __bf16 *__restrict__ src, int64_t ld,
+                                                              int64_t batch_stride, int N, int Np, int H,
+                                                              __bf16 *__restrict__ dst) {
+    __shared__ __attribute__((aligned(16))) __bf16 tile[64 * kPadRow];
+    const int n0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+    const __bf16 *s = src + b * batch_stride + (int64_t)h * kHD;
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int row = c >> 3, col = (c & 7) * 8;
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+        if (n0 + row < N) v = *reinterpret_cast<const bf16x8 *>(s + (int64_t)(n0 + row) * ld + col);
+        *reinterpret_cast<bf16x8 *>(tile + row * kPadRow + col) = v;
+    }
+    __syncthreads();
+    __bf16 *d = dst + ((int64_t)(b * H + h) * kHD) * Np + n0;
+    for (int c = threadIdx.x; c < 512; c += 256) {
+        const int drow = c >> 3, k0 = (c & 7) * 8;
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = tile[(k0 + j) * kPadRow + drow];
+        *reinterpret_cast<bf16x8 *>(d + (int64_t)drow * Np + k0) = v;
+    }
+}
+
+}  // namespace attn
+}  // namespace vah

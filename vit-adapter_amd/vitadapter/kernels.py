@@ -9,6 +9,66 @@ import torch
 import _vah  # noqa: F401  (hard requirement: raises ImportError when the .so is not built)
 
 
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _attention_math(qkv, scale, dropout_p=0.):
+    """Library-GEMM statement of the same arithmetic (fp32 models, head_dim != 64, dropout)."""
+    q, k, v = qkv.permute(2, 0, 3, 1, 4).unbind(0)          # each (B, heads, N, hd)
+    attn = (q @ k.transpose(-2, -1)) * scale
+    attn = attn.softmax(dim=-1)
+    if dropout_p > 0.:
+        attn = torch.nn.functional.dropout(attn, dropout_p, True)
+    return (attn @ v).transpose(1, 2)
+
+
+class _FlashAttention(torch.autograd.Function):
+    """bf16 MFMA attention on the packed qkv projection (csrc/attn_fwd.hip, attn_bwd.hip)."""
+
+    @staticmethod
+    def forward(ctx, qkv, scale):
+        B, N, three, H, hd = qkv.shape
+        qkv = qkv.contiguous()
+        C = H * hd
+        out = torch.empty((B, N, H, hd), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
+        Np = _vah.lib.vah_attn_padded_len(N)
+        ws = torch.empty((B * H * hd * Np,), dtype=qkv.dtype, device=qkv.device)
+        base = qkv.data_ptr()
+        esz = qkv.element_size()
+        with torch.cuda.device(qkv.device):
+            rc = _vah.lib.vah_attn_fwd_bf16(base, base + C * esz, base + 2 * C * esz, 3 * C, N * 3 * C,
+                                            B, H, N, float(scale), ws.data_ptr(), out.data_ptr(), C,
+                                            lse.data_ptr(), _stream(qkv))
+        _vah.check(rc, 'vah_attn_fwd_bf16')
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        return _attention_backward(qkv, out, lse, dout.contiguous().to(qkv.dtype), ctx.scale), None
+
+
+def _attention_backward(qkv, out, lse, dout, scale):
+    """d(loss)/d(qkv) as one packed (B, N, 3, heads, 64) tensor (csrc/attn_bwd.hip)."""
+    B, N, _, H, hd = qkv.shape
+    C = H * hd
+    dqkv = torch.empty_like(qkv)
+    ws = torch.empty((_vah.lib.vah_attn_bwd_workspace_bytes(B, H, N),), dtype=torch.uint8,
+                     device=qkv.device)
+    base, dbase, esz = qkv.data_ptr(), dqkv.data_ptr(), qkv.element_size()
+    with torch.cuda.device(qkv.device):
+        rc = _vah.lib.vah_attn_bwd_bf16(
+            base, base + C * esz, base + 2 * C * esz, 3 * C, N * 3 * C, out.data_ptr(),
+            dout.data_ptr(), C, lse.data_ptr(), B, H, N, float(scale), ws.data_ptr(),
+            dbase, dbase + C * esz, dbase + 2 * C * esz, 3 * C, N * 3 * C, _stream(qkv))
+    _vah.check(rc, 'vah_attn_bwd_bf16')
+    return dqkv
+
+
 def attention(qkv, scale, dropout_p=0.):
     """Softmax attention on a packed projection.
 
@@ -17,9 +77,10 @@ def attention(qkv, scale, dropout_p=0.):
     (/root/reference/detection/mmdet_custom/models/backbones/base/vit.py:83-88,154-159):
     softmax(q k^T * scale) v, with dropout on the probabilities in training.
     """
-    q, k, v = qkv.permute(2, 0, 3, 1, 4).unbind(0)          # each (B, heads, N, hd)
-    attn = (q @ k.transpose(-2, -1)) * scale
-    attn = attn.softmax(dim=-1)
-    if dropout_p > 0.:
-        attn = torch.nn.functional.dropout(attn, dropout_p, True)
-    return (attn @ v).transpose(1, 2)
+    if (qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.shape[-1] == 64 and dropout_p == 0.
+            and qkv.shape[1] > 0 and not FLAGS['force_math_attention']):
+        return _FlashAttention.apply(qkv, scale)
+    return _attention_math(qkv, scale, dropout_p)
+
+
+FLAGS = {'force_math_attention': False}
