@@ -119,29 +119,23 @@ def cpu_baseline(args, preset_kw):
 
 def main():
     args = parse()
-    rank = int(os.environ.get('RANK', '0'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
-        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
 
     import _vah
+    from vitadapter import data_parallel as dp
     from vitadapter.backbones.vit_adapter import PRESETS, ViTAdapter
+
+    rank, local_rank, world = dp.init_from_env('nccl')
+    assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
 
     preset_kw = dict(PRESETS[args.preset])
     torch.manual_seed(0)
     model = ViTAdapter(**preset_kw).to(dev).train()
     n_params = sum(p.numel() for p in model.parameters())
-    net = model
-    if world > 1:
-        net = torch.nn.parallel.DistributedDataParallel(
-            model, device_ids=[local_rank], bucket_cap_mb=64, gradient_as_bucket_view=True,
-            broadcast_buffers=False)
+    net = dp.wrap(model, dev, bucket_cap_mb=64)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.05, fused=True)
     amp = torch.bfloat16 if args.dtype == 'bf16' else None
 
@@ -160,8 +154,7 @@ def main():
         return loss
 
     def fence():
-        if world > 1:
-            dist.barrier()
+        dp.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -177,10 +170,7 @@ def main():
     prof = _vah.prof_report()
     assert torch.isfinite(loss).item(), 'loss is not finite'
 
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt = dp.max_over_ranks(dt, dev)
 
     if rank == 0:
         ips = world * args.batch * args.steps / dt
@@ -228,7 +218,7 @@ def main():
             line['cpu_baseline'] = cpu_baseline(args, preset_kw)
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
+        dp.barrier()
         dist.destroy_process_group()
 
 

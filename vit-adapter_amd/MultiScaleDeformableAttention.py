@@ -86,10 +86,18 @@ def build_query_schedule(reference_points, value_shapes, halo=4.5, n_points=4):
             tot += (min(ch + 2 * halo, h)) * (min(cw + 2 * halo, w))
         return tot
 
+    L = len(value_shapes)
+    lds_bytes = 160 * 1024 - 512
+
+    def fits(core):
+        """grad windows + the group's sample descriptors (32 B each) must fit one workgroup's LDS"""
+        group = Lq * (core * core) / float(H0 * W0) * 1.1
+        return need(core) * 1.15 * 128 + group * L * n_points * 32 <= lds_bytes
+
     core = _env_int('VAH_MSDA_TILE', 0)
     if core <= 0:
         core = 4
-        while core * 2 <= max(H0, W0) and need(core * 2) <= bwd_budget:
+        while core * 2 <= max(H0, W0) and need(core * 2) <= bwd_budget and fits(core * 2):
             core *= 2
     th, tw = max(1, -(-H0 // core)), max(1, -(-W0 // core))
     ty = (ref[:, 1] * H0 / core).floor().clamp_(0, th - 1).long()
