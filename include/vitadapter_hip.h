@@ -159,6 +159,42 @@ int vah_attn_bwd_bf16(const void *q, const void *k, const void *v, int64_t ld, i
                       void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Fused memory-bound operators of the blocks.  They replace
+ * chains of separate PyTorch elementwise / cast / copy kernels in the reference's graph; each is
+ * one pass over its operands.  All tensors dense row-major; C % 4 == 0.
+ *
+ * LayerNorm over the last dim, fp32 in -> bf16 out (reference: nn.LayerNorm(eps=1e-6) followed by
+ * autocast's fp32->bf16 cast in front of every Linear; detection/.../base/vit.py:301-306).
+ * mean / rstd (rows) are saved for the backward.  Column reductions (dw, db, dgamma, conv weight
+ * grads) go through per-workgroup partial rows in a scratch buffer `ws` of
+ * vah_reduce_ws_floats(K) floats (K = number of reduced columns) and a finalize kernel: no atomics,
+ * bitwise reproducible, outputs are overwritten.
+ */
+int64_t vah_reduce_ws_floats(int64_t K);
+int vah_layernorm_fwd_f32_bf16(const float *x, const float *w, const float *b, int64_t rows, int64_t C,
+                               float eps, void *y_bf16, float *mean, float *rstd, void *stream);
+int vah_layernorm_bwd_f32_bf16(const float *x, const void *g_bf16, const float *w, const float *mean,
+                               const float *rstd, int64_t rows, int64_t C,
+                               float *dx, float *dw, float *db, float *ws /* K = 2C */, void *stream);
+/* y = x + s[b] * gamma[c] * z   (x, y fp32 (batch, rows_per_batch, C); z bf16; gamma (C) or NULL;
+ * s (batch) or NULL): the residual update  x + drop_path(gamma * branch(x))  of base/vit.py:301-306
+ * and adapter_modules.py:112-117,145.  Backward: dz (bf16) and dgamma (NULL when gamma is NULL;
+ * ws K = C); dx is the incoming gradient itself. */
+int vah_scale_residual_fwd(const float *x, const void *z_bf16, const float *gamma, const float *s,
+                           int64_t batch, int64_t rows_per_batch, int64_t C, float *y, void *stream);
+int vah_scale_residual_bwd(const float *g, const void *z_bf16, const float *gamma, const float *s,
+                           int64_t batch, int64_t rows_per_batch, int64_t C,
+                           void *dz_bf16, float *dgamma, float *ws, void *stream);
+/* ConvFFN's depthwise 3x3 (+bias) directly on the (B, 21n, C) bf16 token tensor that holds the
+ * (2H,2W), (H,W), (H/2,W/2) maps back to back (segmentation/.../adapter_modules.py:72-87).
+ * mode 0: y = conv(x) + bias; mode 1: input gradient (x = grad of y, flipped taps).
+ * wgrad writes dw (C*9) and db (C or NULL); ws K = 10C. */
+int vah_dwconv3x3_tokens_bf16(const void *x, const float *w, const float *bias, int64_t B, int64_t H,
+                              int64_t W, int64_t C, int mode, void *y, void *stream);
+int vah_dwconv3x3_tokens_wgrad_bf16(const void *x, const void *g, int64_t B, int64_t H, int64_t W,
+                                    int64_t C, float *dw, float *db, float *ws, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Launch timing (bench.py's roofline leg).  While enabled, every kernel launched through
  * this library is bracketed by two hipEvents recorded on the launch's own stream.
  *   vah_prof_enable(1)  : start collecting (drops anything collected before)

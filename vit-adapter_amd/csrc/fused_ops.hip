@@ -1,0 +1,532 @@
+// Fused memory-bound operators of the ViT-Adapter blocks for gfx950 (all HBM-bound: one pass over
+// the activations each, 16-byte accesses, fp32 math).
+//
+//   layernorm_f32_bf16     y = LN(x) over the last dim, fp32 in -> bf16 out (the next op is always a
+//                          bf16 GEMM under autocast: the separate fp32->bf16 cast pass disappears);
+//                          backward produces dx (fp32), dweight, dbias in one pass
+//   scale_residual         y = x + s[b] * gamma[c] * z     x,y fp32 residual stream, z bf16 branch
+//                          output, gamma = layer-scale (optional), s[b] = DropPath mask / keep
+//                          (optional): replaces mul, div, mul, add kernels of
+//                          x + drop_path(gamma * f(x))  (ref: detection/mmdet_custom/models/backbones/
+//                          base/vit.py:301-306); backward gives dz (bf16) and dgamma
+//   dwconv3x3_tokens       the ConvFFN depthwise 3x3 (+bias) applied directly on the (B, 21n, C)
+//                          token tensor whose three level maps are concatenated along the token axis
+//                          (ref: segmentation/mmseg_custom/models/backbones/adapter_modules.py:72-87):
+//                          no slice / transpose / contiguous / cat copies, no MIOpen naive bf16
+//                          depthwise kernels (3.3 ms per step measured)
+#include "common.h"
+
+namespace vah {
+namespace {
+
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+
+__device__ __forceinline__ float wave_sum(float x) {
+    x = dpp_sum16(x);
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
+
+constexpr int kMaxVecAll = 8;    // float4 groups per lane: C <= 64 * 4 * 8 = 2048 (template NV <= 8)
+
+// ---------------------------------------------------------------------------------------
+// LayerNorm forward: one wave per row
+// ---------------------------------------------------------------------------------------
+template <int kMaxVec>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x,
+                                                     const float *__restrict__ w,
+                                                     const float *__restrict__ b, int64_t rows, int C,
+                                                     float eps, __bf16 *__restrict__ y,
+                                                     float *__restrict__ mean, float *__restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = C >> 2;
+    const float *xr = x + row * C;
+    float4 v[kMaxVec];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxVec; ++j) {
+        const int i = lane + 64 * j;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nvec) v[j] = *reinterpret_cast<const float4 *>(xr + 4 * i);
+        s += v[j].x + v[j].y + v[j].z + v[j].w;
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxVec; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nvec) {
+            const float a = v[j].x - mu, b2 = v[j].y - mu, c = v[j].z - mu, d = v[j].w - mu;
+            q += a * a + b2 * b2 + c * c + d * d;
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+    __bf16 *yr = y + row * C;
+#pragma unroll
+    for (int j = 0; j < kMaxVec; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nvec) {
+            const float4 ww = *reinterpret_cast<const float4 *>(w + 4 * i);
+            const float4 bb = *reinterpret_cast<const float4 *>(b + 4 * i);
+            bf16x4 o;
+            o[0] = (__bf16)((v[j].x - mu) * rs * ww.x + bb.x);
+            o[1] = (__bf16)((v[j].y - mu) * rs * ww.y + bb.y);
+            o[2] = (__bf16)((v[j].z - mu) * rs * ww.z + bb.z);
+            o[3] = (__bf16)((v[j].w - mu) * rs * ww.w + bb.w);
+            *reinterpret_cast<bf16x4 *>(yr + 4 * i) = o;
+        }
+    }
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+}
+
+// Column sums that every workgroup contributes to (dweight, dbias, dgamma, conv weight grads) are
+// NOT accumulated with atomics: thousands of workgroups adding into the same few 128-byte lines run
+// an order of magnitude below the atomic rate (measured: the atomic version made the whole training
+// step 15 % slower).  Each workgroup writes one row of partials; finalize_partials sums the rows.
+constexpr int kMaxParts = 1024;
+
+__global__ __launch_bounds__(256) void finalize_partials(const float *__restrict__ part, int nparts,
+                                                         int K, float *__restrict__ out0, int K0,
+                                                         float *__restrict__ out1) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    float acc = 0.f;
+    for (int p = 0; p < nparts; ++p) acc += part[(int64_t)p * K + k];
+    if (k < K0) out0[k] = acc;
+    else if (out1) out1[k - K0] = acc;
+}
+
+// LayerNorm backward: a wave walks rows (grid stride), keeps per-column dw/db partials in
+// registers; the 4 waves of a workgroup are summed through LDS into one partial row [dw | db].
+template <int kMaxVec>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ x,
+                                                     const __bf16 *__restrict__ g,
+                                                     const float *__restrict__ w,
+                                                     const float *__restrict__ mean,
+                                                     const float *__restrict__ rstd, int64_t rows, int C,
+                                                     float *__restrict__ dx, float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float s_red[];      // [4][2C]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nvec = C >> 2;
+    float4 ww[kMaxVec], aw[kMaxVec], ab[kMaxVec];
+#pragma unroll
+    for (int j = 0; j < kMaxVec; ++j) {
+        const int i = lane + 64 * j;
+        ww[j] = aw[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nvec) ww[j] = *reinterpret_cast<const float4 *>(w + 4 * i);
+    }
+    const float invC = 1.f / (float)C;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        const float *xr = x + row * C;
+        const __bf16 *gr = g + row * C;
+        float4 xh[kMaxVec], gw[kMaxVec];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMaxVec; ++j) {
+            const int i = lane + 64 * j;
+            xh[j] = gw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < nvec) {
+                const float4 xv = *reinterpret_cast<const float4 *>(xr + 4 * i);
+                const bf16x4 gv = *reinterpret_cast<const bf16x4 *>(gr + 4 * i);
+                const float g0 = (float)gv[0], g1 = (float)gv[1], g2 = (float)gv[2], g3 = (float)gv[3];
+                xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                gw[j] = make_float4(g0 * ww[j].x, g1 * ww[j].y, g2 * ww[j].z, g3 * ww[j].w);
+                s1 += gw[j].x + gw[j].y + gw[j].z + gw[j].w;
+                s2 += gw[j].x * xh[j].x + gw[j].y * xh[j].y + gw[j].z * xh[j].z + gw[j].w * xh[j].w;
+                aw[j].x += g0 * xh[j].x;
+                aw[j].y += g1 * xh[j].y;
+                aw[j].z += g2 * xh[j].z;
+                aw[j].w += g3 * xh[j].w;
+                ab[j].x += g0;
+                ab[j].y += g1;
+                ab[j].z += g2;
+                ab[j].w += g3;
+            }
+        }
+        const float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
+        float *dr = dx + row * C;
+#pragma unroll
+        for (int j = 0; j < kMaxVec; ++j) {
+            const int i = lane + 64 * j;
+            if (i < nvec)
+                *reinterpret_cast<float4 *>(dr + 4 * i) =
+                    make_float4(rs * (gw[j].x - m1 - xh[j].x * m2), rs * (gw[j].y - m1 - xh[j].y * m2),
+                                rs * (gw[j].z - m1 - xh[j].z * m2), rs * (gw[j].w - m1 - xh[j].w * m2));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kMaxVec; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nvec) {
+            *reinterpret_cast<float4 *>(s_red + wv * 2 * C + 4 * i) = aw[j];
+            *reinterpret_cast<float4 *>(s_red + wv * 2 * C + C + 4 * i) = ab[j];
+        }
+    }
+    __syncthreads();
+    float *pr = part + (int64_t)blockIdx.x * 2 * C;
+    for (int k = threadIdx.x; k < 2 * C; k += 256)
+        pr[k] = s_red[k] + s_red[2 * C + k] + s_red[4 * C + k] + s_red[6 * C + k];
+}
+
+// ---------------------------------------------------------------------------------------
+// y = x + s[b] * gamma[c] * z
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void scale_residual_fwd_kernel(
+    const float *__restrict__ x, const __bf16 *__restrict__ z, const float *__restrict__ gamma,
+    const float *__restrict__ s, int64_t rows_per_batch, int C, int64_t total_vec, float *__restrict__ y) {
+    const int nvec = C >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / nvec;
+        const int cv = (int)(i - row * nvec);
+        const float sb = s ? s[row / rows_per_batch] : 1.f;
+        const float4 xv = *reinterpret_cast<const float4 *>(x + 4 * i);
+        const bf16x4 zv = *reinterpret_cast<const bf16x4 *>(z + 4 * i);
+        float4 gm = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (gamma) gm = *reinterpret_cast<const float4 *>(gamma + 4 * cv);
+        *reinterpret_cast<float4 *>(y + 4 * i) =
+            make_float4(xv.x + sb * gm.x * (float)zv[0], xv.y + sb * gm.y * (float)zv[1],
+                        xv.z + sb * gm.z * (float)zv[2], xv.w + sb * gm.w * (float)zv[3]);
+    }
+}
+
+// dz = s[b] * gamma * g (bf16);  dgamma[c] += sum s[b] * g * z.  One thread owns one float4 column
+// group and walks a strip of rows, so dgamma partials stay in registers.
+__global__ __launch_bounds__(256) void scale_residual_bwd_kernel(
+    const float *__restrict__ g, const __bf16 *__restrict__ z, const float *__restrict__ gamma,
+    const float *__restrict__ s, int64_t rows, int64_t rows_per_batch, int C, int rows_per_block,
+    __bf16 *__restrict__ dz, float *__restrict__ part) {
+    const int nvec = C >> 2;
+    const int64_t row0 = (int64_t)blockIdx.x * rows_per_block;
+    for (int cv = threadIdx.x; cv < nvec; cv += 256) {
+        float4 gm = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (gamma) gm = *reinterpret_cast<const float4 *>(gamma + 4 * cv);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int rr = 0; rr < rows_per_block; ++rr) {
+            const int64_t row = row0 + rr;
+            if (row >= rows) break;
+            const float sb = s ? s[row / rows_per_batch] : 1.f;
+            const int64_t off = row * C + 4 * cv;
+            const float4 gv = *reinterpret_cast<const float4 *>(g + off);
+            const bf16x4 zv = *reinterpret_cast<const bf16x4 *>(z + off);
+            bf16x4 o;
+            o[0] = (__bf16)(sb * gm.x * gv.x);
+            o[1] = (__bf16)(sb * gm.y * gv.y);
+            o[2] = (__bf16)(sb * gm.z * gv.z);
+            o[3] = (__bf16)(sb * gm.w * gv.w);
+            *reinterpret_cast<bf16x4 *>(dz + off) = o;
+            acc.x += sb * gv.x * (float)zv[0];
+            acc.y += sb * gv.y * (float)zv[1];
+            acc.z += sb * gv.z * (float)zv[2];
+            acc.w += sb * gv.w * (float)zv[3];
+        }
+        if (part) *reinterpret_cast<float4 *>(part + (int64_t)blockIdx.x * C + 4 * cv) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// depthwise 3x3 on the concatenated token maps
+// ---------------------------------------------------------------------------------------
+struct Maps {          // token ranges [t0, t1) of the 3 maps and their (h, w)
+    int t[4];
+    int h[3], w[3];
+};
+
+__device__ __forceinline__ int map_of(const Maps &mp, int tok) { return tok >= mp.t[2] ? 2 : (tok >= mp.t[1] ? 1 : 0); }
+
+// mode 0: out = conv(x) + bias      (weights as given)
+// mode 1: out = conv with the flipped kernel (input gradient), no bias
+template <int MODE>
+__global__ __launch_bounds__(256) void dwconv_kernel(const __bf16 *__restrict__ x,
+                                                     const float *__restrict__ w,
+                                                     const float *__restrict__ bias, Maps mp, int N,
+                                                     int C, int64_t total_vec, __bf16 *__restrict__ y) {
+    const int nvec = C >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
+        const int64_t tokg = i / nvec;                  // b * N + tok
+        const int cv = (int)(i - tokg * nvec);
+        const int tok = (int)(tokg % N);
+        const int64_t b = tokg / N;
+        const int m = map_of(mp, tok);
+        const int H = mp.h[m], W = mp.w[m], t0 = mp.t[m];
+        const int py = (tok - t0) / W, px = (tok - t0) - py * W;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 0 && bias) acc = *reinterpret_cast<const float4 *>(bias + 4 * cv);
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = py + dy, xx = px + dx;
+                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                const bf16x4 v = *reinterpret_cast<const bf16x4 *>(
+                    x + ((b * N + t0 + (int64_t)yy * W + xx) * C + 4 * cv));
+                // weight layout (C, 1, 3, 3): tap index (dy+1)*3 + (dx+1); flipped for MODE 1
+                const int tap = MODE == 0 ? (dy + 1) * 3 + (dx + 1) : (1 - dy) * 3 + (1 - dx);
+                acc.x += w[(4 * cv + 0) * 9 + tap] * (float)v[0];
+                acc.y += w[(4 * cv + 1) * 9 + tap] * (float)v[1];
+                acc.z += w[(4 * cv + 2) * 9 + tap] * (float)v[2];
+                acc.w += w[(4 * cv + 3) * 9 + tap] * (float)v[3];
+            }
+        bf16x4 o;
+        o[0] = (__bf16)acc.x;
+        o[1] = (__bf16)acc.y;
+        o[2] = (__bf16)acc.z;
+        o[3] = (__bf16)acc.w;
+        *reinterpret_cast<bf16x4 *>(y + 4 * i) = o;
+    }
+}
+
+// dw[c][tap] = sum_tok g[tok,c] * x[neighbour(tok,tap), c];  db[c] = sum g.  Thread = (token slot,
+// channel group): walks tokens with a grid stride, 40 partial sums in registers; the slots of a
+// workgroup are summed through LDS into one partial row [dw (C*9) | db (C)].
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const __bf16 *__restrict__ x,
+                                                           const __bf16 *__restrict__ g, Maps mp, int N,
+                                                           int C, int64_t total_tok,
+                                                           float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float s_red[];      // [slots][C*10]
+    const int nvec = C >> 2;
+    const int slots = 256 / nvec;                    // token slots per block (>= 1 when C <= 1024)
+    const int slot = threadIdx.x / nvec, cv = threadIdx.x - slot * nvec;
+    const bool live = slot < slots;
+    float aw[4][9], ab[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) aw[c][t] = 0.f;
+    if (live)
+        for (int64_t tokg = (int64_t)blockIdx.x * slots + slot; tokg < total_tok; tokg += (int64_t)gridDim.x * slots) {
+            const int tok = (int)(tokg % N);
+            const int64_t b = tokg / N;
+            const int m = map_of(mp, tok);
+            const int H = mp.h[m], W = mp.w[m], t0 = mp.t[m];
+            const int py = (tok - t0) / W, px = (tok - t0) - py * W;
+            const bf16x4 gv = *reinterpret_cast<const bf16x4 *>(g + tokg * C + 4 * cv);
+            const float gf[4] = {(float)gv[0], (float)gv[1], (float)gv[2], (float)gv[3]};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ab[c] += gf[c];
+#pragma unroll
+            for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int yy = py + dy, xx = px + dx;
+                    if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
+                    const bf16x4 v = *reinterpret_cast<const bf16x4 *>(
+                        x + ((b * N + t0 + (int64_t)yy * W + xx) * C + 4 * cv));
+                    const int tap = (dy + 1) * 3 + (dx + 1);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) aw[c][tap] += gf[c] * (float)v[c];
+                }
+        }
+    const int K = C * 10;
+    if (live) {
+        float *r = s_red + slot * K;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) r[(4 * cv + c) * 9 + t] = aw[c][t];
+            r[C * 9 + 4 * cv + c] = ab[c];
+        }
+    }
+    __syncthreads();
+    float *pr = part + (int64_t)blockIdx.x * K;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        float acc = 0.f;
+        for (int sl = 0; sl < slots; ++sl) acc += s_red[sl * K + k];
+        pr[k] = acc;
+    }
+}
+
+inline unsigned grid_for(int64_t work_items, int per_block) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    const int64_t cap = (int64_t)kCUs * 16;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (unsigned)g;
+}
+
+}  // namespace
+}  // namespace vah
+
+extern "C" {
+
+int vah_layernorm_fwd_f32_bf16(const float *x, const float *w, const float *b, int64_t rows,
+                               int64_t C, float eps, void *y, float *mean, float *rstd, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_layernorm_fwd_f32_bf16";
+    if (rows < 0 || C < 4 || C % 4 || C > 64 * 4 * kMaxVecAll) return fail(VAH_E_SHAPE, "%s: C=%lld unsupported", fn, (long long)C);
+    if (rows == 0) return VAH_OK;
+    if (!x || !w || !b || !y || !mean || !rstd) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)b) % 16 || (uintptr_t)y % 8) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    hipStream_t st = (hipStream_t)stream;
+    LaunchScope scope("layernorm_fwd", rows * C * 6, st);
+#define VAH_LN_FWD(NV)                                                                          \
+    hipLaunchKernelGGL(ln_fwd_kernel<NV>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, w, b, \
+                       rows, (int)C, eps, (__bf16 *)y, mean, rstd)
+    if (C <= 256) VAH_LN_FWD(1);
+    else if (C <= 512) VAH_LN_FWD(2);
+    else if (C <= 1024) VAH_LN_FWD(4);
+    else VAH_LN_FWD(8);
+#undef VAH_LN_FWD
+    return check_launch(fn);
+}
+
+int64_t vah_reduce_ws_floats(int64_t K) { return (int64_t)vah::kMaxParts * K; }
+
+// ws: vah_reduce_ws_floats(2*C) floats of scratch.  dw, db are overwritten.
+int vah_layernorm_bwd_f32_bf16(const float *x, const void *g, const float *w, const float *mean,
+                               const float *rstd, int64_t rows, int64_t C, float *dx, float *dw,
+                               float *db, float *ws, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_layernorm_bwd_f32_bf16";
+    if (rows < 0 || C < 4 || C % 4 || C > 64 * 4 * kMaxVecAll) return fail(VAH_E_SHAPE, "%s: C=%lld unsupported", fn, (long long)C);
+    if (!dw || !db || !ws) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) {
+        (void)hipMemsetAsync(dw, 0, C * 4, st);
+        (void)hipMemsetAsync(db, 0, C * 4, st);
+        return VAH_OK;
+    }
+    if (!x || !g || !w || !mean || !rstd || !dx) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)dx) % 16 || (uintptr_t)g % 8) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    int64_t nblocks = (rows + 3) / 4;
+    if (nblocks > kMaxParts) nblocks = kMaxParts;
+    const size_t smem = (size_t)8 * C * sizeof(float);
+    LaunchScope scope("layernorm_bwd", rows * C * 10, st);
+#define VAH_LN_BWD(NV)                                                                          \
+    hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3((unsigned)nblocks), dim3(256), smem, st, x,      \
+                       (const __bf16 *)g, w, mean, rstd, rows, (int)C, dx, ws)
+    if (C <= 256) VAH_LN_BWD(1);
+    else if (C <= 512) VAH_LN_BWD(2);
+    else if (C <= 1024) VAH_LN_BWD(4);
+    else VAH_LN_BWD(8);
+#undef VAH_LN_BWD
+    hipLaunchKernelGGL(finalize_partials, dim3((unsigned)((2 * C + 255) / 256)), dim3(256), 0, st, ws,
+                       (int)nblocks, (int)(2 * C), dw, (int)C, db);
+    return check_launch(fn);
+}
+
+int vah_scale_residual_fwd(const float *x, const void *z, const float *gamma, const float *s,
+                           int64_t batch, int64_t rows_per_batch, int64_t C, float *y, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_scale_residual_fwd";
+    if (batch < 0 || rows_per_batch < 0 || C < 4 || C % 4) return fail(VAH_E_SHAPE, "%s: bad dims", fn);
+    const int64_t total_vec = batch * rows_per_batch * (C / 4);
+    if (total_vec == 0) return VAH_OK;
+    if (!x || !z || !y) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma) % 16 || (uintptr_t)z % 8) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    hipStream_t st = (hipStream_t)stream;
+    LaunchScope scope("scale_residual_fwd", total_vec * 40, st);
+    hipLaunchKernelGGL(scale_residual_fwd_kernel, dim3(grid_for(total_vec, 256 * 4)), dim3(256), 0, st, x,
+                       (const __bf16 *)z, gamma, s, rows_per_batch, (int)C, total_vec, y);
+    return check_launch(fn);
+}
+
+// dgamma (may be NULL when gamma is NULL) is overwritten; ws: vah_reduce_ws_floats(C) floats.
+int vah_scale_residual_bwd(const float *g, const void *z, const float *gamma, const float *s,
+                           int64_t batch, int64_t rows_per_batch, int64_t C, void *dz, float *dgamma,
+                           float *ws, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_scale_residual_bwd";
+    if (batch < 0 || rows_per_batch < 0 || C < 4 || C % 4) return fail(VAH_E_SHAPE, "%s: bad dims", fn);
+    const int64_t rows = batch * rows_per_batch;
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) {
+        if (dgamma) (void)hipMemsetAsync(dgamma, 0, C * 4, st);
+        return VAH_OK;
+    }
+    if (!g || !z || !dz || (dgamma && !ws)) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if (((uintptr_t)g | (uintptr_t)gamma) % 16 || ((uintptr_t)z | (uintptr_t)dz) % 8) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    const int rpb = (int)((rows + kMaxParts - 1) / kMaxParts);
+    const int64_t nblocks = (rows + rpb - 1) / rpb;
+    LaunchScope scope("scale_residual_bwd", rows * C * 8, st);
+    hipLaunchKernelGGL(scale_residual_bwd_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, g,
+                       (const __bf16 *)z, gamma, s, rows, rows_per_batch, (int)C, rpb, (__bf16 *)dz,
+                       dgamma ? ws : nullptr);
+    if (dgamma)
+        hipLaunchKernelGGL(finalize_partials, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, ws,
+                           (int)nblocks, (int)C, dgamma, (int)C, (float *)nullptr);
+    return check_launch(fn);
+}
+
+// x, y: bf16 (B, N, C) with N = 16n + 4n + n tokens of maps (2H,2W), (H,W), (H/2,W/2); w fp32 (C,1,3,3).
+// mode 0: forward (+bias); mode 1: input gradient (x = grad_out, flipped taps, bias ignored).
+int vah_dwconv3x3_tokens_bf16(const void *x, const float *w, const float *bias, int64_t B, int64_t H,
+                              int64_t W, int64_t C, int mode, void *y, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_dwconv3x3_tokens_bf16";
+    if (B < 0 || H < 2 || W < 2 || (H % 2) || (W % 2) || C < 4 || C % 4) return fail(VAH_E_SHAPE, "%s: bad dims", fn);
+    if (B == 0) return VAH_OK;
+    if (!x || !w || !y) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if (((uintptr_t)x | (uintptr_t)y) % 8 || (uintptr_t)bias % 16) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    const int64_t n = (H / 2) * (W / 2);
+    Maps mp;
+    mp.t[0] = 0, mp.t[1] = (int)(16 * n), mp.t[2] = (int)(20 * n), mp.t[3] = (int)(21 * n);
+    mp.h[0] = (int)(2 * H), mp.w[0] = (int)(2 * W), mp.h[1] = (int)H, mp.w[1] = (int)W;
+    mp.h[2] = (int)(H / 2), mp.w[2] = (int)(W / 2);
+    const int N = (int)(21 * n);
+    const int64_t total_vec = B * N * (C / 4);
+    hipStream_t st = (hipStream_t)stream;
+    LaunchScope scope(mode == 0 ? "dwconv_tokens_fwd" : "dwconv_tokens_dgrad", total_vec * 16, st);
+    if (mode == 0)
+        hipLaunchKernelGGL(dwconv_kernel<0>, dim3(grid_for(total_vec, 256 * 2)), dim3(256), 0, st,
+                           (const __bf16 *)x, w, bias, mp, N, (int)C, total_vec, (__bf16 *)y);
+    else
+        hipLaunchKernelGGL(dwconv_kernel<1>, dim3(grid_for(total_vec, 256 * 2)), dim3(256), 0, st,
+                           (const __bf16 *)x, w, bias, mp, N, (int)C, total_vec, (__bf16 *)y);
+    return check_launch(fn);
+}
+
+// dw (C*9) and db (C, may be NULL) are overwritten; ws: vah_reduce_ws_floats(10*C) floats.
+int vah_dwconv3x3_tokens_wgrad_bf16(const void *x, const void *g, int64_t B, int64_t H, int64_t W,
+                                    int64_t C, float *dw, float *db, float *ws, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_dwconv3x3_tokens_wgrad_bf16";
+    if (B < 0 || H < 2 || W < 2 || (H % 2) || (W % 2) || C < 4 || C % 4 || C > 1024) return fail(VAH_E_SHAPE, "%s: bad dims", fn);
+    if (!dw || !ws) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        (void)hipMemsetAsync(dw, 0, C * 9 * 4, st);
+        if (db) (void)hipMemsetAsync(db, 0, C * 4, st);
+        return VAH_OK;
+    }
+    if (!x || !g) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if (((uintptr_t)x | (uintptr_t)g) % 8) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    const int64_t n = (H / 2) * (W / 2);
+    Maps mp;
+    mp.t[0] = 0, mp.t[1] = (int)(16 * n), mp.t[2] = (int)(20 * n), mp.t[3] = (int)(21 * n);
+    mp.h[0] = (int)(2 * H), mp.w[0] = (int)(2 * W), mp.h[1] = (int)H, mp.w[1] = (int)W;
+    mp.h[2] = (int)(H / 2), mp.w[2] = (int)(W / 2);
+    const int N = (int)(21 * n);
+    const int64_t total_tok = B * N;
+    const int slots = 256 / (int)(C / 4);
+    int64_t nblocks = (total_tok + slots * 16 - 1) / (slots * 16);
+    if (nblocks > kMaxParts) nblocks = kMaxParts;
+    if (nblocks < 1) nblocks = 1;
+    const size_t smem = (size_t)slots * C * 10 * sizeof(float);
+    if (smem > 150 * 1024) return fail(VAH_E_SHAPE, "%s: C too small for the LDS reduction layout", fn);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)dwconv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
+        attr_set = true;
+    }
+    LaunchScope scope("dwconv_tokens_wgrad", total_tok * C * 4, st);
+    hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((unsigned)nblocks), dim3(256), smem, st,
+                       (const __bf16 *)x, (const __bf16 *)g, mp, N, (int)C, total_tok, ws);
+    hipLaunchKernelGGL(finalize_partials, dim3((unsigned)((10 * C + 255) / 256)), dim3(256), 0, st, ws,
+                       (int)nblocks, (int)(10 * C), dw, (int)(9 * C), db);
+    return check_launch(fn);
+}
+
+}  // extern "C"

@@ -18,6 +18,7 @@ import torch.nn as nn
 import torch.utils.checkpoint as cp
 from ops.modules import MSDeformAttn
 
+from .. import fused
 from .vit import DropPath
 
 
@@ -72,6 +73,9 @@ class DWConv(nn.Module):
         self.dwconv = nn.Conv2d(dim, dim, 3, 1, 1, bias=True, groups=dim)
 
     def forward(self, x, H, W):
+        y = fused.dwconv_tokens(self.dwconv, x, H, W)      # one HIP kernel on the token layout
+        if y is not None:
+            return y
         B, N, C = x.shape
         n = N // 21
         outs = []
@@ -119,11 +123,13 @@ class Extractor(nn.Module):
 
     def forward(self, query, reference_points, feat, spatial_shapes, level_start_index, H, W):
         def body(query, feat):
-            query = query + self.attn(self.query_norm(query), reference_points,
-                                      self.feat_norm(feat), spatial_shapes, level_start_index,
-                                      None)
+            attn = self.attn(fused.layer_norm(self.query_norm, query), reference_points,
+                             fused.layer_norm(self.feat_norm, feat), spatial_shapes,
+                             level_start_index, None)
+            query = fused.residual(query, attn)
             if self.with_cffn:
-                query = query + self.drop_path(self.ffn(self.ffn_norm(query), H, W))
+                query = fused.residual(query, self.ffn(fused.layer_norm(self.ffn_norm, query), H, W),
+                                       None, self.drop_path)
             return query
 
         if self.with_cp and query.requires_grad:
@@ -146,9 +152,10 @@ class Injector(nn.Module):
 
     def forward(self, query, reference_points, feat, spatial_shapes, level_start_index):
         def body(query, feat):
-            return query + self.gamma * self.attn(self.query_norm(query), reference_points,
-                                                  self.feat_norm(feat), spatial_shapes,
-                                                  level_start_index, None)
+            attn = self.attn(fused.layer_norm(self.query_norm, query), reference_points,
+                             fused.layer_norm(self.feat_norm, feat), spatial_shapes,
+                             level_start_index, None)
+            return fused.residual(query, attn, self.gamma)
 
         if self.with_cp and query.requires_grad:
             return cp.checkpoint(body, query, feat, use_reentrant=False)

@@ -19,7 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as cp
 
-from .. import kernels
+from .. import fused, kernels
 
 
 def to_2tuple(x):
@@ -214,10 +214,12 @@ class Block(nn.Module):
                                                act_layer=act_layer)
 
     def _body(self, x, H, W):
-        a = self.attn(self.norm1(x), H, W)
-        x = x + self.drop_path(self.gamma1 * a if self.layer_scale else a)
-        f = self.mlp(self.norm2(x))
-        x = x + self.drop_path(self.gamma2 * f if self.layer_scale else f)
+        # x + drop_path(gamma1 * attn(norm1(x))), x + drop_path(gamma2 * mlp(norm2(x)))
+        # (ref base/vit.py:301-306); fused.* fall back to exactly that expression off the bf16 path
+        a = self.attn(fused.layer_norm(self.norm1, x), H, W)
+        x = fused.residual(x, a, self.gamma1 if self.layer_scale else None, self.drop_path)
+        f = self.mlp(fused.layer_norm(self.norm2, x))
+        x = fused.residual(x, f, self.gamma2 if self.layer_scale else None, self.drop_path)
         if self.use_residual:
             B, N, C = x.shape
             y = self.residual(x.reshape(B, H, W, C).permute(0, 3, 1, 2))
