@@ -63,6 +63,25 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("VAH_CPU_THREADS", "16"))))
 
 
+def pmc_traffic(kernel, args, preset_kw):
+    """HBM bytes per launch of the dominant MSDA kernel from the committed PMC pass
+    (profiles/r01_msda_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+    tools/prof_msda_single.py, gfx950 FETCH_SIZE x2 correction).  Only for the exact shapes that
+    pass measured (BASELINE configs[2]: 4 injector + 6 extractor calls per direction and step);
+    None otherwise."""
+    if args.preset != 'base_det' or list(args.size) != [1024, 1024] or args.batch != 2:
+        return None
+    path = os.path.join(ROOT, 'profiles', 'r01_msda_pmc.json')
+    try:
+        pmc = json.load(open(path))
+        d = 'fwd' if 'fwd' in kernel else 'bwd'
+        inj = pmc['cfg3_inj_' + d]['hbm_bytes_per_launch']
+        ext = pmc['cfg3_ext_' + d]['hbm_bytes_per_launch']
+        return int((4 * inj + 6 * ext) / 10)
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(args, preset_kw):
     """Oracle (CPU port of the reference) on the host cores; bounded sample, same workload."""
     from oracle import cases, msda as oracle_msda, seeded, vit_adapter_ref as ref
@@ -191,7 +210,8 @@ def main():
             dom = max(msda, key=lambda k: msda[k]['ms_per_step'])
             a = msda[dom]['achieved_GBps']
             roofline = {'kernel': dom, 'bound': 'hbm', 'achieved': a, 'peak': HBM_PEAK / 1e9,
-                        'unit': 'GB/s', 'frac': round(a / (HBM_PEAK / 1e9), 4), 'traffic': None,
+                        'unit': 'GB/s', 'frac': round(a / (HBM_PEAK / 1e9), 4),
+                        'traffic': pmc_traffic(dom, args, preset_kw),
                         'avg_launch_us': msda[dom]['avg_us'],
                         'algorithmic_bytes_per_launch': msda[dom]['bytes_per_launch']}
         line = {

@@ -23,6 +23,8 @@
 //     reference: no host sync anywhere.
 #include "common.h"
 
+#include <cstdlib>
+
 namespace vah {
 namespace {
 
@@ -97,7 +99,11 @@ constexpr int kBlock = 256;
 // ---------------------------------------------------------------------------------------
 // Forward, f32, D = 4*LANES: LANES lanes x float4 per row.
 // ---------------------------------------------------------------------------------------
-template <int LANES, int PU>
+// QMAJOR: consecutive lane groups take consecutive QUERIES of one head (work index = (n, m, q))
+// instead of consecutive heads of one query.  Neighbouring queries sample overlapping corner rows,
+// so the 8 rows a wave instruction asks for collapse to fewer distinct cache lines in the TA and
+// neighbouring waves re-hit L1: less L2 -> L1 traffic, which is what bounds this kernel.
+template <int LANES, int PU, bool QMAJOR>
 __global__ __launch_bounds__(kBlock) void msda_fwd_vec4(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
@@ -108,10 +114,20 @@ __global__ __launch_bounds__(kBlock) void msda_fwd_vec4(
     const int64_t blk = xcd_chunked_block(nblocks);
     if (blk >= nblocks) return;
     const int sub = threadIdx.x % LANES;
-    const int64_t row = blk * ROWS + threadIdx.x / LANES;
-    if (row >= total_rows) return;
-    const int m = (int)(row % M);
-    const int64_t n = row / M / Lq;
+    const int64_t work = blk * ROWS + threadIdx.x / LANES;
+    if (work >= total_rows) return;
+    int m;
+    int64_t n, row;
+    if (QMAJOR) {
+        const int64_t q = work % Lq;
+        m = (int)((work / Lq) % M);
+        n = work / Lq / M;
+        row = (n * Lq + q) * M + m;
+    } else {
+        row = work;
+        m = (int)(row % M);
+        n = row / M / Lq;
+    }
     const int64_t stride = (int64_t)M * D;                       // floats per token
     const float *vhead = value + n * S * stride + m * D + sub * 4;
     const float *lp = loc + row * (int64_t)(L * P) * 2;
@@ -405,10 +421,21 @@ int launch_fwd_vec4(const Dims &d, const float *value, const int64_t *shapes, co
     const int64_t nblocks = (d.rows + ROWS - 1) / ROWS;
     const int64_t grid = (nblocks + 7) / 8 * 8;
     if (grid >= ((int64_t)1 << 31)) return fail(VAH_E_SHAPE, "msda forward: grid too large");
-#define VAH_FWD(PU)                                                                            \
-    hipLaunchKernelGGL((msda_fwd_vec4<LANES, PU>), dim3((unsigned)grid), dim3(kBlock), 0, st,  \
-                       value, shapes, lsi, loc, attn, d.S, (int)d.M, (int)d.L, d.Lq, (int)d.P, \
-                       d.rows, nblocks, out)
+    static const bool qmajor = [] {
+        const char *e = getenv("VAH_MSDA_FWD_QMAJOR");
+        return e ? atoi(e) != 0 : true;
+    }();
+#define VAH_FWD(PU)                                                                               \
+    do {                                                                                          \
+        if (qmajor)                                                                               \
+            hipLaunchKernelGGL((msda_fwd_vec4<LANES, PU, true>), dim3((unsigned)grid), dim3(kBlock), 0, \
+                               st, value, shapes, lsi, loc, attn, d.S, (int)d.M, (int)d.L, d.Lq,   \
+                               (int)d.P, d.rows, nblocks, out);                                    \
+        else                                                                                      \
+            hipLaunchKernelGGL((msda_fwd_vec4<LANES, PU, false>), dim3((unsigned)grid), dim3(kBlock), 0, \
+                               st, value, shapes, lsi, loc, attn, d.S, (int)d.M, (int)d.L, d.Lq,   \
+                               (int)d.P, d.rows, nblocks, out);                                    \
+    } while (0)
     if (d.P % 4 == 0) VAH_FWD(4);
     else if (d.P % 2 == 0) VAH_FWD(2);
     else VAH_FWD(1);
