@@ -47,6 +47,9 @@ def parse():
     ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'full', 'small', 'none'],
                     help="auto: 'full' (one 1024^2 image) at N=1 on rank 0, none otherwise")
     ap.add_argument('--no-optimizer', action='store_true', help='diagnostic only: skip AdamW')
+    ap.add_argument('--gemm-tuning', default='file', choices=['file', 'off', 'tune'],
+                    help="hipBLASLt/rocBLAS solution selection through torch TunableOp: 'file' loads the "
+                         "committed selections (no tuning at run time), 'tune' re-tunes and rewrites them")
     return ap.parse_args()
 
 
@@ -61,6 +64,30 @@ def host_cores():
     except (OSError, ValueError):
         pass
     return max(1, min(n, int(os.environ.get("VAH_CPU_THREADS", "16"))))
+
+
+TUNING_FILE = os.path.join(ROOT, 'vit-adapter_amd', 'tuning', 'tunableop_gemm_mi355x_base_det_1024.csv')
+
+
+def setup_gemm_tuning(args):
+    """The Linear layers run on hipBLASLt / rocBLAS through torch.  Their default heuristic picks
+    slow tiles for several of this workload's shapes; torch's TunableOp selections, tuned once on an
+    MI355X and committed (vit-adapter_amd/tuning/), are replayed here (57.7 vs 60.9 ms per step).
+    Shapes that are not in the file keep the library default."""
+    if args.gemm_tuning == 'off':
+        return
+    import torch.cuda.tunable as tunable
+    tunable.enable(True)
+    if args.gemm_tuning == 'tune':
+        tunable.tuning_enable(True)
+        tunable.set_max_tuning_duration(30)
+        tunable.set_filename(TUNING_FILE)
+    else:
+        tunable.tuning_enable(False)
+        if hasattr(tunable, 'write_file_on_exit'):
+            tunable.write_file_on_exit(False)
+        if os.path.exists(TUNING_FILE):
+            tunable.read_file(TUNING_FILE)
 
 
 def pmc_traffic(kernel, args, preset_kw):
@@ -150,6 +177,7 @@ def main():
     rank, local_rank, world = dp.init_from_env('nccl')
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
 
+    setup_gemm_tuning(args)
     preset_kw = dict(PRESETS[args.preset])
     torch.manual_seed(0)
     model = ViTAdapter(**preset_kw).to(dev).train()
