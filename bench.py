@@ -47,6 +47,9 @@ def parse():
     ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'full', 'small', 'none'],
                     help="auto: 'full' (one 1024^2 image) at N=1 on rank 0, none otherwise")
     ap.add_argument('--no-optimizer', action='store_true', help='diagnostic only: skip AdamW')
+    ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
+                    help="'gloo' lets several ranks share one GPU for a functional rehearsal of the "
+                         "N>1 path on a 1-GPU box (not a performance mode)")
     ap.add_argument('--gemm-tuning', default='file', choices=['file', 'off', 'tune'],
                     help="hipBLASLt/rocBLAS solution selection through torch TunableOp: 'file' loads the "
                          "committed selections (no tuning at run time), 'tune' re-tunes and rewrites them")
@@ -167,14 +170,15 @@ def main():
     args = parse()
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
 
     import _vah
     from vitadapter import data_parallel as dp
     from vitadapter.backbones.vit_adapter import PRESETS, ViTAdapter
 
-    rank, local_rank, world = dp.init_from_env('nccl')
+    rank, local_rank, world = dp.init_from_env(args.backend)
     assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
 
     setup_gemm_tuning(args)

@@ -28,7 +28,7 @@ def init_from_env(backend=None):
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         kw = {}
         if backend == 'nccl':
-            kw['device_id'] = torch.device('cuda', local_rank)
+            kw['device_id'] = torch.device('cuda', local_rank % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
 
