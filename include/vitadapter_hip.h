@@ -127,6 +127,33 @@ int vah_msda_backward_win_f32(const float *value, const int64_t *shapes, const i
                               float *grad_value, float *grad_loc, float *grad_attn, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Fused MSDeformAttn core: softmax over the L*P attention logits +
+ * sampling-location arithmetic + the gather in one kernel, and their gradients in one more.
+ * Replaces lines 108-128 of /root/reference/detection/ops/modules/ms_deform_attn.py.
+ *
+ *   value     (N,S,M,32)        value_dtype: 0 = fp32, 1 = bf16   (out and grad_out use this dtype)
+ *   offsets   (N,Lq,M,L,P,2)    raw sampling_offsets Linear output, param_dtype 0 = fp32 / 1 = bf16
+ *   logits    (N,Lq,M,L*P)      raw attention_weights Linear output (softmax is done in-kernel)
+ *   ref       (Lq, ref_levels, 2) fp32 reference points (x, y) in [0,1], ref_levels = 1 or L,
+ *             shared by the batch (the adapter's reference grids)
+ *   location  = ref + offsets / (W_l, H_l)
+ * Supported: D == 32 and (L, P) in {(1,4), (3,4), (4,4)}  (vah_msda_fused_supported).
+ * Backward: grad_value fp32 (N,S,M,32) zero on entry (float atomics); d_offsets / d_logits in
+ * param_dtype, fully written.
+ * ------------------------------------------------------------------------------------ */
+int vah_msda_fused_supported(int64_t D, int64_t L, int64_t P);
+int vah_msda_fused_forward(const void *value, int value_dtype, const int64_t *shapes, const int64_t *lsi,
+                           const void *offsets, const void *logits, int param_dtype,
+                           const float *ref, int64_t ref_levels,
+                           int64_t N, int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P,
+                           void *out, void *stream);
+int vah_msda_fused_backward(const void *value, int value_dtype, const int64_t *shapes, const int64_t *lsi,
+                            const void *offsets, const void *logits, int param_dtype,
+                            const float *ref, int64_t ref_levels, const void *grad_out,
+                            int64_t N, int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P,
+                            float *grad_value, void *d_offsets, void *d_logits, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Softmax attention of the ViT blocks, bf16, head_dim 64  
  *
  * Replaces the score / softmax / value products of the reference's Attention and

@@ -186,3 +186,45 @@ def test_full_size_pyramid_shapes_and_finiteness():
     assert all(torch.isfinite(o).all() for o in outs)
     grads = [p.grad for p in model.parameters() if p.grad is not None]
     assert len(grads) > 300 and all(torch.isfinite(g).all() for g in grads)
+
+
+@pytest.mark.parametrize('name', ['inj_t', 'ext_b'])
+def test_msdeformattn_module_unfused_path_matches_reference(golden_dir, name, monkeypatch):
+    """Same goldens through the reference's own op sequence (softmax / location arithmetic in
+    PyTorch + MSDeformAttnFunction), i.e. with the fused core switched off."""
+    monkeypatch.setenv('VAH_MSDA_FUSED', '0')
+    test_msdeformattn_module_matches_reference(golden_dir, name)
+
+
+@pytest.mark.parametrize('L,shapes,qshapes', [(3, [(16, 16), (8, 8), (4, 4)], [(8, 8)]),
+                                              (1, [(8, 8)], [(16, 16), (8, 8), (4, 4)]),
+                                              (4, [(8, 8), (4, 4), (2, 2), (1, 1)], [(8, 8), (4, 4), (2, 2), (1, 1)])])
+def test_fused_core_bf16_autocast_matches_unfused(monkeypatch, L, shapes, qshapes):
+    """Under bf16 autocast the fused core reads the bf16 Linear outputs directly; the unfused
+    sequence casts them to fp32 first.  Same information, so results agree to bf16 rounding."""
+    from ops.modules import MSDeformAttn
+    torch.manual_seed(4)
+    m = MSDeformAttn(d_model=192, n_levels=L, n_heads=6, n_points=4, ratio=1.0).cuda()
+    with torch.no_grad():
+        m.sampling_offsets.weight.normal_(0, 0.02)
+        m.attention_weights.weight.normal_(0, 0.05)
+    S, Lq = sum(h * w for h, w in shapes), sum(h * w for h, w in qshapes)
+    ref = cases.reference_grid(qshapes).cuda()
+    hw = torch.as_tensor(shapes, dtype=torch.long).cuda()
+    lsi = cases.level_start_index(shapes).cuda()
+    query = torch.randn(2, Lq, 192, device='cuda')
+    feat = torch.randn(2, S, 192, device='cuda')
+    gout = torch.randn(2, Lq, 192, device='cuda')
+    res = []
+    for fused in ('1', '0'):
+        monkeypatch.setenv('VAH_MSDA_FUSED', fused)
+        qq, ff = query.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+        m.zero_grad()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out = m(qq, ref, ff, hw, lsi, None)
+        out.float().backward(gout)
+        res.append((out.float(), qq.grad, ff.grad, m.sampling_offsets.weight.grad.clone(),
+                    m.attention_weights.bias.grad.clone(), m.value_proj.weight.grad.clone()))
+    for a, b, nm in zip(res[0], res[1], ('out', 'dquery', 'dfeat', 'd offsets.w', 'd attn.b', 'd value.w')):
+        err = (a - b).abs().max().item()
+        assert err <= 4e-2 * max(1.0, b.abs().max().item()), (nm, err)

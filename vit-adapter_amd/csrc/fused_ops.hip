@@ -260,22 +260,32 @@ __device__ __forceinline__ int map_of(const Maps &mp, int tok) { return tok >= m
 
 // mode 0: out = conv(x) + bias      (weights as given)
 // mode 1: out = conv with the flipped kernel (input gradient), no bias
+// Thread = (token slot, channel group of 4): the 36 filter taps of its channels stay in registers
+// while it walks tokens with a grid stride (a per-output reload of the taps made the kernel
+// 8x slower than its memory traffic allows).
 template <int MODE>
 __global__ __launch_bounds__(256) void dwconv_kernel(const __bf16 *__restrict__ x,
                                                      const float *__restrict__ w,
                                                      const float *__restrict__ bias, Maps mp, int N,
-                                                     int C, int64_t total_vec, __bf16 *__restrict__ y) {
+                                                     int C, int64_t total_tok, __bf16 *__restrict__ y) {
     const int nvec = C >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * 256) {
-        const int64_t tokg = i / nvec;                  // b * N + tok
-        const int cv = (int)(i - tokg * nvec);
+    const int slots = 256 / nvec;
+    const int slot = threadIdx.x / nvec, cv = threadIdx.x - slot * nvec;
+    if (slot >= slots) return;
+    float wt[4][9];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wt[c][t] = w[(4 * cv + c) * 9 + (MODE == 0 ? t : 8 - t)];
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (MODE == 0 && bias) b4 = *reinterpret_cast<const float4 *>(bias + 4 * cv);
+    for (int64_t tokg = (int64_t)blockIdx.x * slots + slot; tokg < total_tok; tokg += (int64_t)gridDim.x * slots) {
         const int tok = (int)(tokg % N);
         const int64_t b = tokg / N;
         const int m = map_of(mp, tok);
         const int H = mp.h[m], W = mp.w[m], t0 = mp.t[m];
         const int py = (tok - t0) / W, px = (tok - t0) - py * W;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (MODE == 0 && bias) acc = *reinterpret_cast<const float4 *>(bias + 4 * cv);
+        float4 acc = b4;
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy)
 #pragma unroll
@@ -284,19 +294,18 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const __bf16 *__restrict__ 
                 if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
                 const bf16x4 v = *reinterpret_cast<const bf16x4 *>(
                     x + ((b * N + t0 + (int64_t)yy * W + xx) * C + 4 * cv));
-                // weight layout (C, 1, 3, 3): tap index (dy+1)*3 + (dx+1); flipped for MODE 1
-                const int tap = MODE == 0 ? (dy + 1) * 3 + (dx + 1) : (1 - dy) * 3 + (1 - dx);
-                acc.x += w[(4 * cv + 0) * 9 + tap] * (float)v[0];
-                acc.y += w[(4 * cv + 1) * 9 + tap] * (float)v[1];
-                acc.z += w[(4 * cv + 2) * 9 + tap] * (float)v[2];
-                acc.w += w[(4 * cv + 3) * 9 + tap] * (float)v[3];
+                const int tap = (dy + 1) * 3 + (dx + 1);     // flipped taps already folded into wt
+                acc.x += wt[0][tap] * (float)v[0];
+                acc.y += wt[1][tap] * (float)v[1];
+                acc.z += wt[2][tap] * (float)v[2];
+                acc.w += wt[3][tap] * (float)v[3];
             }
         bf16x4 o;
         o[0] = (__bf16)acc.x;
         o[1] = (__bf16)acc.y;
         o[2] = (__bf16)acc.z;
         o[3] = (__bf16)acc.w;
-        *reinterpret_cast<bf16x4 *>(y + 4 * i) = o;
+        *reinterpret_cast<bf16x4 *>(y + tokg * C + 4 * cv) = o;
     }
 }
 
@@ -483,7 +492,7 @@ int vah_dwconv3x3_tokens_bf16(const void *x, const float *w, const float *bias, 
     using namespace vah;
     clear_error();
     const char *fn = "vah_dwconv3x3_tokens_bf16";
-    if (B < 0 || H < 2 || W < 2 || (H % 2) || (W % 2) || C < 4 || C % 4) return fail(VAH_E_SHAPE, "%s: bad dims", fn);
+    if (B < 0 || H < 2 || W < 2 || (H % 2) || (W % 2) || C < 4 || C % 4 || C > 1024) return fail(VAH_E_SHAPE, "%s: bad dims", fn);
     if (B == 0) return VAH_OK;
     if (!x || !w || !y) return fail(VAH_E_NULL, "%s: null pointer", fn);
     if (((uintptr_t)x | (uintptr_t)y) % 8 || (uintptr_t)bias % 16) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
@@ -493,15 +502,16 @@ int vah_dwconv3x3_tokens_bf16(const void *x, const float *w, const float *bias, 
     mp.h[0] = (int)(2 * H), mp.w[0] = (int)(2 * W), mp.h[1] = (int)H, mp.w[1] = (int)W;
     mp.h[2] = (int)(H / 2), mp.w[2] = (int)(W / 2);
     const int N = (int)(21 * n);
-    const int64_t total_vec = B * N * (C / 4);
+    const int64_t total_tok = B * N;
+    const int slots = 256 / (int)(C / 4);
     hipStream_t st = (hipStream_t)stream;
-    LaunchScope scope(mode == 0 ? "dwconv_tokens_fwd" : "dwconv_tokens_dgrad", total_vec * 16, st);
+    LaunchScope scope(mode == 0 ? "dwconv_tokens_fwd" : "dwconv_tokens_dgrad", total_tok * C * 4, st);
     if (mode == 0)
-        hipLaunchKernelGGL(dwconv_kernel<0>, dim3(grid_for(total_vec, 256 * 2)), dim3(256), 0, st,
-                           (const __bf16 *)x, w, bias, mp, N, (int)C, total_vec, (__bf16 *)y);
+        hipLaunchKernelGGL(dwconv_kernel<0>, dim3(grid_for(total_tok, slots * 4)), dim3(256), 0, st,
+                           (const __bf16 *)x, w, bias, mp, N, (int)C, total_tok, (__bf16 *)y);
     else
-        hipLaunchKernelGGL(dwconv_kernel<1>, dim3(grid_for(total_vec, 256 * 2)), dim3(256), 0, st,
-                           (const __bf16 *)x, w, bias, mp, N, (int)C, total_vec, (__bf16 *)y);
+        hipLaunchKernelGGL(dwconv_kernel<1>, dim3(grid_for(total_tok, slots * 4)), dim3(256), 0, st,
+                           (const __bf16 *)x, w, bias, mp, N, (int)C, total_tok, (__bf16 *)y);
     return check_launch(fn);
 }
 

@@ -18,7 +18,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from ..functions import MSDeformAttnFunction
+from ..functions import MSDeformAttnFunction, MSDeformAttnFusedFunction, fused_supported
 
 _SCHEDULES = {}
 
@@ -110,8 +110,13 @@ class MSDeformAttn(nn.Module):
         value = value.view(N, S, M, value.shape[-1] // M)
 
         offsets = self.sampling_offsets(query).view(N, Lq, M, L, P, 2)
-        weights = F.softmax(self.attention_weights(query).view(N, Lq, M, L * P), -1)
-        weights = weights.view(N, Lq, M, L, P)
+        logits = self.attention_weights(query).view(N, Lq, M, L * P)
+        if fused_supported(value, offsets, logits, reference_points, L, P):
+            # softmax + location arithmetic + gather in one kernel (csrc/msda_fused.hip)
+            out = MSDeformAttnFusedFunction.apply(value, input_spatial_shapes, input_level_start_index,
+                                                  offsets, logits, reference_points)
+            return self.output_proj(out)
+        weights = F.softmax(logits, -1).view(N, Lq, M, L, P)
 
         if reference_points.shape[-1] == 2:
             wh = input_spatial_shapes.flip(-1).to(offsets.dtype)          # (L, 2) as (W, H)
