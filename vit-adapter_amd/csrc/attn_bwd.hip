@@ -53,9 +53,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
     const __bf16 *__restrict__ kt, const __bf16 *__restrict__ d_o, int64_t ld, int64_t batch_stride,
     int64_t ld_out, const float *__restrict__ lse, const float *__restrict__ delta, int N, int Np,
     int H, float scale, float scale_log2, __bf16 *__restrict__ dq, int64_t ld_d, int64_t batch_stride_d) {
-    __shared__ __attribute__((aligned(16))) __bf16 s_k[64 * kPadRow];
-    __shared__ __attribute__((aligned(16))) __bf16 s_v[64 * kPadRow];
-    __shared__ __attribute__((aligned(16))) __bf16 s_kt[kHD * kPadT];
+    // double buffered (one barrier per key tile)
+    __shared__ __attribute__((aligned(16))) __bf16 s_k2[2][64 * kPadRow];
+    __shared__ __attribute__((aligned(16))) __bf16 s_v2[2][64 * kPadRow];
+    __shared__ __attribute__((aligned(16))) __bf16 s_kt2[2][kHD * kPadT];
 
     const int h = blockIdx.y, b = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -96,7 +97,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
         pt0 = *reinterpret_cast<const bf16x8 *>(ktb + (int64_t)r0 * Np + key0 + x0);
         pt1 = *reinterpret_cast<const bf16x8 *>(ktb + (int64_t)r1 * Np + key0 + x1);
     };
-    auto commit = [&]() {
+    auto commit = [&](int buf) {
+        __bf16 *s_k = s_k2[buf], *s_v = s_v2[buf], *s_kt = s_kt2[buf];
         *reinterpret_cast<bf16x8 *>(s_k + r0 * kPadRow + x0) = pk0;
         *reinterpret_cast<bf16x8 *>(s_k + r1 * kPadRow + x1) = pk1;
         *reinterpret_cast<bf16x8 *>(s_v + r0 * kPadRow + x0) = pv0;
@@ -110,11 +112,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
 
     const int ntiles = (N + 63) / 64;
     fetch(0);
+    commit(0);
+    if (ntiles > 1) fetch(64);
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
-        commit();
-        __syncthreads();
-        if (t + 1 < ntiles) fetch((t + 1) * 64);
+        if (t + 1 < ntiles) {
+            commit((t + 1) & 1);
+            if (t + 2 < ntiles) fetch((t + 2) * 64);
+        }
+        const __bf16 *s_k = s_k2[t & 1], *s_v = s_v2[t & 1], *s_kt = s_kt2[t & 1];
         const int key0 = t * 64;
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk) {
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const bool live = key0 + kbk * 32 + crow(i, hf) < N;
-                const float p = live ? exp2f(s[i] * scale_log2 - lse_q) : 0.f;
+                const float p = live ? __builtin_amdgcn_exp2f(s[i] * scale_log2 - lse_q) : 0.f;
                 s[i] = p * (dp[i] - delta_q);                       // dS^T
             }
 #pragma unroll
@@ -166,12 +172,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
     int64_t ld, int64_t batch_stride, int64_t ld_out, const float *__restrict__ lse,
     const float *__restrict__ delta, int N, int Np, int H, float scale, float scale_log2,
     __bf16 *__restrict__ dk, __bf16 *__restrict__ dv, int64_t ld_d, int64_t batch_stride_d) {
-    __shared__ __attribute__((aligned(16))) __bf16 s_q[32 * kPadRow];
-    __shared__ __attribute__((aligned(16))) __bf16 s_do[32 * kPadRow];
-    __shared__ __attribute__((aligned(16))) __bf16 s_qt[kHD * kPadT32];
-    __shared__ __attribute__((aligned(16))) __bf16 s_dot[kHD * kPadT32];
-    __shared__ __attribute__((aligned(16))) float s_lse[32];
-    __shared__ __attribute__((aligned(16))) float s_delta[32];
+    // double buffered (one barrier per query tile)
+    __shared__ __attribute__((aligned(16))) __bf16 s_q2[2][32 * kPadRow];
+    __shared__ __attribute__((aligned(16))) __bf16 s_do2[2][32 * kPadRow];
+    __shared__ __attribute__((aligned(16))) __bf16 s_qt2[2][kHD * kPadT32];
+    __shared__ __attribute__((aligned(16))) __bf16 s_dot2[2][kHD * kPadT32];
+    __shared__ __attribute__((aligned(16))) float s_lse2[2][32];
+    __shared__ __attribute__((aligned(16))) float s_delta2[2][32];
 
     const int h = blockIdx.y, b = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -218,7 +225,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
             pdel = ok ? delb[q0 + threadIdx.x] : 0.f;
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int buf) {
+        __bf16 *s_q = s_q2[buf], *s_do = s_do2[buf], *s_qt = s_qt2[buf], *s_dot = s_dot2[buf];
+        float *s_lse = s_lse2[buf], *s_delta = s_delta2[buf];
         *reinterpret_cast<bf16x8 *>(s_q + rr * kPadRow + rx) = pq;
         *reinterpret_cast<bf16x8 *>(s_do + rr * kPadRow + rx) = pdo;
         const bf16x4 *a = reinterpret_cast<const bf16x4 *>(&pqt), *g = reinterpret_cast<const bf16x4 *>(&pdot);
@@ -234,11 +243,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
 
     const int ntiles = (N + 31) / 32;
     fetch(0);
+    commit(0);
+    if (ntiles > 1) fetch(32);
     for (int t = 0; t < ntiles; ++t) {
         __syncthreads();
-        commit();
-        __syncthreads();
-        if (t + 1 < ntiles) fetch((t + 1) * 32);
+        if (t + 1 < ntiles) {
+            commit((t + 1) & 1);
+            if (t + 2 < ntiles) fetch((t + 2) * 32);
+        }
+        const __bf16 *s_q = s_q2[t & 1], *s_do = s_do2[t & 1], *s_qt = s_qt2[t & 1], *s_dot = s_dot2[t & 1];
+        const float *s_lse = s_lse2[t & 1], *s_delta = s_delta2[t & 1];
 
         f32x16 s = zero16(), dp = zero16();
 #pragma unroll
@@ -256,7 +270,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int i = 4 * g + j;
-                const float p = key_live ? exp2f(s[i] * scale_log2 - ls[j]) : 0.f;
+                const float p = key_live ? __builtin_amdgcn_exp2f(s[i] * scale_log2 - ls[j]) : 0.f;
                 s[i] = p;                                  // P
                 dp[i] = p * (dp[i] - de[j]);               // dS
             }

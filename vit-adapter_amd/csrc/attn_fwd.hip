@@ -33,8 +33,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
     const __bf16 *__restrict__ q, const __bf16 *__restrict__ k, const __bf16 *__restrict__ vt,
     int64_t ld, int64_t batch_stride, int N, int Np, int H, float scale_log2,
     __bf16 *__restrict__ out, int64_t ld_out, float *__restrict__ lse) {
-    __shared__ __attribute__((aligned(16))) __bf16 s_k[kKTile * kPadRow];
-    __shared__ __attribute__((aligned(16))) __bf16 s_vt[kHD * kPadT];
+    // double buffered: tile t+1 is written while tile t is being multiplied (one barrier per tile)
+    __shared__ __attribute__((aligned(16))) __bf16 s_k2[2][kKTile * kPadRow];
+    __shared__ __attribute__((aligned(16))) __bf16 s_vt2[2][kHD * kPadT];
 
     const int h = blockIdx.y, b = blockIdx.z;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -66,7 +67,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
         pv0 = *reinterpret_cast<const bf16x8 *>(vtb + (int64_t)kr0 * Np + key0 + kc0);
         pv1 = *reinterpret_cast<const bf16x8 *>(vtb + (int64_t)kr1 * Np + key0 + kc1);
     };
-    auto commit = [&]() {
+    auto commit = [&](int buf) {
+        __bf16 *s_k = s_k2[buf], *s_vt = s_vt2[buf];
         *reinterpret_cast<bf16x8 *>(s_k + kr0 * kPadRow + kc0) = pk0;
         *reinterpret_cast<bf16x8 *>(s_k + kr1 * kPadRow + kc1) = pk1;
         // V^T rows are 64 keys wide: two 8-byte halves keep 8-byte alignment under the 136-byte stride
@@ -79,11 +81,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
 
     const int ntiles = (N + kKTile - 1) / kKTile;
     fetch(0);
+    commit(0);
+    if (ntiles > 1) fetch(kKTile);
     for (int t = 0; t < ntiles; ++t) {
-        __syncthreads();                 // previous tile fully consumed
-        commit();
-        __syncthreads();
-        if (t + 1 < ntiles) fetch((t + 1) * kKTile);
+        __syncthreads();                 // tile t visible; every wave is done with tile t-1
+        if (t + 1 < ntiles) {
+            commit((t + 1) & 1);         // overwrites the buffer tile t-1 lived in
+            if (t + 2 < ntiles) fetch((t + 2) * kKTile);
+        }
+        const __bf16 *s_k = s_k2[t & 1], *s_vt = s_vt2[t & 1];
 
         // S^T = K Q^T : two blocks of 32 keys
         f32x16 s[2] = {zero16(), zero16()};
@@ -109,14 +115,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
             for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kbk][i]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx * scale_log2);
-        const float alpha = exp2f(m_run - m_new);       // first tile: exp2(-inf) = 0
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);       // first tile: exp2(-inf) = 0
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
         for (int kbk = 0; kbk < 2; ++kbk)
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const float p = exp2f(s[kbk][i] * scale_log2 - m_new);
+                const float p = __builtin_amdgcn_exp2f(s[kbk][i] * scale_log2 - m_new);
                 s[kbk][i] = p;
                 psum += p;
             }
