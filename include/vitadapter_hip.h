@@ -172,6 +172,17 @@ int vah_attn_fwd_bf16(const void *q, const void *k, const void *v, int64_t ld, i
                       int64_t B, int64_t H, int64_t N, float scale, void *vt_ws,
                       void *out, int64_t ld_out, float *lse, void *stream);
 
+/* Windowed variant (WindowedAttention, base/vit.py:136-167): q, k, v are the fused projection of
+ * a (B, grid_h, grid_w) token grid in its natural row-major token order; the kernels cut it into
+ * win x win windows on the fly (grid padded up to a multiple of win; padded tokens read as zero
+ * q = k = v rows - the reference pads AFTER the projection - take part in the softmax unmasked and
+ * are never written).  No pad / unfold / fold / crop copies.  out uses the same token order.
+ * Sequences Z = B * ceil(grid_h/win) * ceil(grid_w/win), N = win*win tokens each:
+ * lse is (Z, heads, N), vt_ws holds Z*heads*64*vah_attn_padded_len(N) bf16. */
+int vah_attn_win_fwd_bf16(const void *q, const void *k, const void *v, int64_t ld, int64_t B,
+                          int64_t grid_h, int64_t grid_w, int64_t win, int64_t H, float scale,
+                          void *vt_ws, void *out, int64_t ld_out, float *lse, void *stream);
+
 /* Backward of the same op (the reference differentiates the materialised softmax with autograd;
  * here the probabilities are recomputed from q, k and lse).  dq / dk / dv are bf16 and use the
  * addressing of q / k / v with (ld_d, batch_stride_d): pass the three slices of one packed
@@ -184,6 +195,11 @@ int vah_attn_bwd_bf16(const void *q, const void *k, const void *v, int64_t ld, i
                       int64_t B, int64_t H, int64_t N, float scale, void *ws,
                       void *dq, void *dk, void *dv, int64_t ld_d, int64_t batch_stride_d,
                       void *stream);
+/* ws: vah_attn_bwd_workspace_bytes(Z, heads, win*win) bytes. */
+int vah_attn_win_bwd_bf16(const void *q, const void *k, const void *v, int64_t ld,
+                          const void *out, const void *dout, int64_t ld_out, const float *lse,
+                          int64_t B, int64_t grid_h, int64_t grid_w, int64_t win, int64_t H, float scale,
+                          void *ws, void *dq, void *dk, void *dv, int64_t ld_d, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused memory-bound operators of the blocks.  They replace

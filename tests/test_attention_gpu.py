@@ -60,3 +60,32 @@ def test_fp32_and_other_head_dims_use_library_gemms():
     out = kernels.attention(qkv, 32 ** -0.5)
     assert out.dtype == torch.float32
     assert (out - _ref(qkv, 32 ** -0.5)).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize('B,H,W,heads,win', [(2, 10, 17, 2, 14), (1, 14, 14, 3, 14), (2, 64, 64, 2, 14), (1, 5, 3, 1, 4)])
+def test_window_attention_fused_partition(B, H, W, heads, win):
+    """Windows cut by the kernels' addressing vs the reference's sequence (pad AFTER projection,
+    partition, attend, merge, crop; base/vit.py:136-167) evaluated in fp32."""
+    import math
+    import torch.nn.functional as F
+    from vitadapter import kernels
+    torch.manual_seed(H * W)
+    C = heads * 64
+    qkv = (torch.randn(B, H * W, 3, heads, 64, device='cuda') * 1.2).to(torch.bfloat16).requires_grad_(True)
+    scale = 64 ** -0.5
+    out = kernels.window_attention(qkv, scale, H, W, win)
+    assert out is not None and out.shape == (B, H * W, heads, 64)
+    g = torch.randn(B, H * W, heads, 64, device='cuda')
+    out.backward(g.to(torch.bfloat16))
+
+    qr = qkv.detach().float().requires_grad_(True)
+    Hp, Wp = math.ceil(H / win) * win, math.ceil(W / win) * win
+    t = F.pad(qr.view(B, H, W, 3 * C), (0, 0, 0, Wp - W, 0, Hp - H))
+    t = t.view(B, Hp // win, win, Wp // win, win, 3 * C).permute(0, 1, 3, 2, 4, 5)
+    t = t.reshape(-1, win * win, 3, heads, 64)
+    o = _ref(t, scale).reshape(B, Hp // win, Wp // win, win, win, C).permute(0, 1, 3, 2, 4, 5)
+    ref = o.reshape(B, Hp, Wp, C)[:, :H, :W].reshape(B, H * W, heads, 64)
+    ref.backward(g)
+    assert (out.float() - ref).abs().max().item() <= 3e-2 * max(1.0, ref.abs().max().item())
+    gerr = (qkv.grad.float() - qr.grad.view_as(qkv)).abs().max().item()
+    assert gerr <= 6e-2 * max(1.0, qr.grad.abs().max().item()), gerr

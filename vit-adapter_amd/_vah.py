@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -56,6 +56,11 @@ lib.vah_attn_bwd_bf16.argtypes = ([_p, _p, _p, _i64, _i64, _p, _p, _i64, _p, _i6
                                   + [_p] * 4 + [_i64, _i64, _p])
 lib.vah_attn_bwd_bf16.restype = ctypes.c_int
 
+lib.vah_attn_win_fwd_bf16.argtypes = [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, _i64, ctypes.c_float, _p, _p, _i64, _p, _p]
+lib.vah_attn_win_fwd_bf16.restype = ctypes.c_int
+lib.vah_attn_win_bwd_bf16.argtypes = [_p, _p, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, _i64, ctypes.c_float,
+                                      _p, _p, _p, _p, _i64, _p]
+lib.vah_attn_win_bwd_bf16.restype = ctypes.c_int
 _ci = ctypes.c_int
 lib.vah_msda_fused_supported.argtypes = [_i64, _i64, _i64]
 lib.vah_msda_fused_supported.restype = ctypes.c_int
@@ -88,6 +93,7 @@ EXPORTS = (
     'vah_msda_forward_win_f32', 'vah_msda_backward_win_f32',
     'vah_msda_fused_supported', 'vah_msda_fused_forward', 'vah_msda_fused_backward',
     'vah_attn_padded_len', 'vah_attn_fwd_bf16', 'vah_attn_bwd_workspace_bytes', 'vah_attn_bwd_bf16',
+    'vah_attn_win_fwd_bf16', 'vah_attn_win_bwd_bf16',
     'vah_reduce_ws_floats', 'vah_layernorm_fwd_f32_bf16', 'vah_layernorm_bwd_f32_bf16', 'vah_scale_residual_fwd',
     'vah_scale_residual_bwd', 'vah_dwconv3x3_tokens_bf16', 'vah_dwconv3x3_tokens_wgrad_bf16',
 )

@@ -22,25 +22,28 @@ namespace vah {
 namespace attn {
 namespace {
 
-// delta[b,h,n] = sum_d dO[b,n,h,d] * O[b,n,h,d]
+// delta[z,h,i] = sum_d dO[row,h,d] * O[row,h,d]   (0 for padded tokens)
 __global__ __launch_bounds__(256) void attn_delta_kernel(const __bf16 *__restrict__ o,
                                                          const __bf16 *__restrict__ d_o, int64_t ld_out,
-                                                         int N, int H, int64_t total,
+                                                         RowMap rm, int N, int H, int64_t total,
                                                          float *__restrict__ delta) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // over (b, h, n), n fastest
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // over (z, h, n), n fastest
     if (i >= total) return;
     const int n = (int)(i % N);
     const int h = (int)((i / N) % H);
-    const int64_t b = i / N / H;
-    const __bf16 *po = o + (b * N + n) * ld_out + (int64_t)h * kHD;
-    const __bf16 *pd = d_o + (b * N + n) * ld_out + (int64_t)h * kHD;
+    const int z = (int)(i / N / H);
+    const int64_t gr = grow(rm, z, n, N);
     float acc = 0.f;
+    if (gr >= 0) {
+        const __bf16 *po = o + gr * ld_out + (int64_t)h * kHD;
+        const __bf16 *pd = d_o + gr * ld_out + (int64_t)h * kHD;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8 *>(po + 8 * c);
-        const bf16x8 g = *reinterpret_cast<const bf16x8 *>(pd + 8 * c);
+        for (int c = 0; c < 8; ++c) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(po + 8 * c);
+            const bf16x8 g = *reinterpret_cast<const bf16x8 *>(pd + 8 * c);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)g[j];
+            for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)g[j];
+        }
     }
     delta[i] = acc;
 }
@@ -50,9 +53,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const __bf16 *__restric
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
     const __bf16 *__restrict__ q, const __bf16 *__restrict__ k, const __bf16 *__restrict__ v,
-    const __bf16 *__restrict__ kt, const __bf16 *__restrict__ d_o, int64_t ld, int64_t batch_stride,
+    const __bf16 *__restrict__ kt, const __bf16 *__restrict__ d_o, int64_t ld, RowMap rm,
     int64_t ld_out, const float *__restrict__ lse, const float *__restrict__ delta, int N, int Np,
-    int H, float scale, float scale_log2, __bf16 *__restrict__ dq, int64_t ld_d, int64_t batch_stride_d) {
+    int H, float scale, float scale_log2, __bf16 *__restrict__ dq, int64_t ld_d) {
     // double buffered (one barrier per key tile)
     __shared__ __attribute__((aligned(16))) __bf16 s_k2[2][64 * kPadRow];
     __shared__ __attribute__((aligned(16))) __bf16 s_v2[2][64 * kPadRow];
@@ -64,17 +67,22 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
     const int qrow = blockIdx.x * 128 + wave * 32 + r;
     const int qload = min(qrow, N - 1);
 
-    const __bf16 *qb = q + b * batch_stride + (int64_t)h * kHD;
-    const __bf16 *kb = k + b * batch_stride + (int64_t)h * kHD;
-    const __bf16 *vb = v + b * batch_stride + (int64_t)h * kHD;
+    const __bf16 *qb = q + (int64_t)h * kHD;
+    const __bf16 *kb = k + (int64_t)h * kHD;
+    const __bf16 *vb = v + (int64_t)h * kHD;
     const __bf16 *ktb = kt + ((int64_t)(b * H + h) * kHD) * Np;
-    const __bf16 *dob = d_o + ((int64_t)b * N) * ld_out + (int64_t)h * kHD;
+    const __bf16 *dob = d_o + (int64_t)h * kHD;
+    const int64_t gq = grow(rm, b, qload, N);
 
     bf16x8 qf[4], dof[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-        qf[kk] = *reinterpret_cast<const bf16x8 *>(qb + (int64_t)qload * ld + 16 * kk + 8 * hf);
-        dof[kk] = *reinterpret_cast<const bf16x8 *>(dob + (int64_t)qload * ld_out + 16 * kk + 8 * hf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[kk][j] = dof[kk][j] = (__bf16)0.f;
+        if (gq >= 0) {
+            qf[kk] = *reinterpret_cast<const bf16x8 *>(qb + gq * ld + 16 * kk + 8 * hf);
+            dof[kk] = *reinterpret_cast<const bf16x8 *>(dob + gq * ld_out + 16 * kk + 8 * hf);
+        }
     }
     const float lse_q = lse[((int64_t)b * H + h) * N + qload];
     const float delta_q = delta[((int64_t)b * H + h) * N + qload];
@@ -86,13 +94,15 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
     auto fetch = [&](int key0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) pk0[j] = pk1[j] = pv0[j] = pv1[j] = (__bf16)0.f;
-        if (key0 + r0 < N) {
-            pk0 = *reinterpret_cast<const bf16x8 *>(kb + (int64_t)(key0 + r0) * ld + x0);
-            pv0 = *reinterpret_cast<const bf16x8 *>(vb + (int64_t)(key0 + r0) * ld + x0);
+        const int64_t g0 = key0 + r0 < N ? grow(rm, b, key0 + r0, N) : -1;
+        const int64_t g1 = key0 + r1 < N ? grow(rm, b, key0 + r1, N) : -1;
+        if (g0 >= 0) {
+            pk0 = *reinterpret_cast<const bf16x8 *>(kb + g0 * ld + x0);
+            pv0 = *reinterpret_cast<const bf16x8 *>(vb + g0 * ld + x0);
         }
-        if (key0 + r1 < N) {
-            pk1 = *reinterpret_cast<const bf16x8 *>(kb + (int64_t)(key0 + r1) * ld + x1);
-            pv1 = *reinterpret_cast<const bf16x8 *>(vb + (int64_t)(key0 + r1) * ld + x1);
+        if (g1 >= 0) {
+            pk1 = *reinterpret_cast<const bf16x8 *>(kb + g1 * ld + x1);
+            pv1 = *reinterpret_cast<const bf16x8 *>(vb + g1 * ld + x1);
         }
         pt0 = *reinterpret_cast<const bf16x8 *>(ktb + (int64_t)r0 * Np + key0 + x0);
         pt1 = *reinterpret_cast<const bf16x8 *>(ktb + (int64_t)r1 * Np + key0 + x1);
@@ -149,8 +159,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
             }
         }
     }
-    if (qrow < N) {
-        __bf16 *op = dq + b * batch_stride_d + (int64_t)qrow * ld_d + (int64_t)h * kHD;
+    if (qrow < N && gq >= 0) {
+        __bf16 *op = dq + gq * ld_d + (int64_t)h * kHD;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -169,9 +179,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
     const __bf16 *__restrict__ q, const __bf16 *__restrict__ k, const __bf16 *__restrict__ v,
     const __bf16 *__restrict__ qt, const __bf16 *__restrict__ d_o, const __bf16 *__restrict__ dot,
-    int64_t ld, int64_t batch_stride, int64_t ld_out, const float *__restrict__ lse,
+    int64_t ld, RowMap rm, int64_t ld_out, const float *__restrict__ lse,
     const float *__restrict__ delta, int N, int Np, int H, float scale, float scale_log2,
-    __bf16 *__restrict__ dk, __bf16 *__restrict__ dv, int64_t ld_d, int64_t batch_stride_d) {
+    __bf16 *__restrict__ dk, __bf16 *__restrict__ dv, int64_t ld_d) {
     // double buffered (one barrier per query tile)
     __shared__ __attribute__((aligned(16))) __bf16 s_q2[2][32 * kPadRow];
     __shared__ __attribute__((aligned(16))) __bf16 s_do2[2][32 * kPadRow];
@@ -185,22 +195,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
     const int r = lane & 31, hf = lane >> 5;
     const int krow = blockIdx.x * 128 + wave * 32 + r;              // this lane's key
     const int kload = min(krow, N - 1);
+    const int64_t gk = grow(rm, b, kload, N);
+    // a padded key is NOT masked: it takes part in the softmax with k = v = 0 (reference quirk),
+    // only its gradient has nowhere to go
     const bool key_live = krow < N;
 
-    const __bf16 *qb = q + b * batch_stride + (int64_t)h * kHD;
-    const __bf16 *kb = k + b * batch_stride + (int64_t)h * kHD;
-    const __bf16 *vb = v + b * batch_stride + (int64_t)h * kHD;
+    const __bf16 *qb = q + (int64_t)h * kHD;
+    const __bf16 *kb = k + (int64_t)h * kHD;
+    const __bf16 *vb = v + (int64_t)h * kHD;
     const __bf16 *qtb = qt + ((int64_t)(b * H + h) * kHD) * Np;
     const __bf16 *dotb = dot + ((int64_t)(b * H + h) * kHD) * Np;
-    const __bf16 *dob = d_o + ((int64_t)b * N) * ld_out + (int64_t)h * kHD;
+    const __bf16 *dob = d_o + (int64_t)h * kHD;
     const float *lseb = lse + ((int64_t)b * H + h) * N;
     const float *delb = delta + ((int64_t)b * H + h) * N;
 
     bf16x8 kf[4], vf[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-        kf[kk] = *reinterpret_cast<const bf16x8 *>(kb + (int64_t)kload * ld + 16 * kk + 8 * hf);
-        vf[kk] = *reinterpret_cast<const bf16x8 *>(vb + (int64_t)kload * ld + 16 * kk + 8 * hf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kf[kk][j] = vf[kk][j] = (__bf16)0.f;
+        if (gk >= 0) {
+            kf[kk] = *reinterpret_cast<const bf16x8 *>(kb + gk * ld + 16 * kk + 8 * hf);
+            vf[kk] = *reinterpret_cast<const bf16x8 *>(vb + gk * ld + 16 * kk + 8 * hf);
+        }
     }
     f32x16 dkt[2] = {zero16(), zero16()}, dvt[2] = {zero16(), zero16()};
 
@@ -213,9 +230,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
     auto fetch = [&](int q0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) pq[j] = pdo[j] = (__bf16)0.f;
-        if (q0 + rr < N) {
-            pq = *reinterpret_cast<const bf16x8 *>(qb + (int64_t)(q0 + rr) * ld + rx);
-            pdo = *reinterpret_cast<const bf16x8 *>(dob + (int64_t)(q0 + rr) * ld_out + rx);
+        const int64_t gr = q0 + rr < N ? grow(rm, b, q0 + rr, N) : -1;
+        if (gr >= 0) {
+            pq = *reinterpret_cast<const bf16x8 *>(qb + gr * ld + rx);
+            pdo = *reinterpret_cast<const bf16x8 *>(dob + gr * ld_out + rx);
         }
         pqt = *reinterpret_cast<const bf16x8 *>(qtb + (int64_t)tr * Np + q0 + tx);
         pdot = *reinterpret_cast<const bf16x8 *>(dotb + (int64_t)tr * Np + q0 + tx);
@@ -287,9 +305,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(
             }
         }
     }
-    if (key_live) {
-        __bf16 *pk = dk + b * batch_stride_d + (int64_t)krow * ld_d + (int64_t)h * kHD;
-        __bf16 *pv = dv + b * batch_stride_d + (int64_t)krow * ld_d + (int64_t)h * kHD;
+    if (key_live && gk >= 0) {
+        __bf16 *pk = dk + gk * ld_d + (int64_t)h * kHD;
+        __bf16 *pv = dv + gk * ld_d + (int64_t)h * kHD;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -317,22 +335,19 @@ int64_t vah_attn_bwd_workspace_bytes(int64_t B, int64_t H, int64_t N) {
     return 3 * B * H * 64 * Np * 2 + (B * H * N * 4 + 15) / 16 * 16;
 }
 
-int vah_attn_bwd_bf16(const void *q, const void *k, const void *v, int64_t ld, int64_t batch_stride,
-                      const void *out, const void *dout, int64_t ld_out, const float *lse, int64_t B,
-                      int64_t H, int64_t N, float scale, void *ws, void *dq, void *dk, void *dv,
-                      int64_t ld_d, int64_t batch_stride_d, void *stream) {
+static int attn_bwd_impl(const char *fn, const void *q, const void *k, const void *v, int64_t ld,
+                         vah::attn::RowMap rm, const void *out, const void *dout, int64_t ld_out,
+                         const float *lse, int64_t B, int64_t H, int64_t N, float scale, void *ws, void *dq,
+                         void *dk, void *dv, int64_t ld_d, void *stream) {
     using namespace vah;
     using namespace vah::attn;
-    clear_error();
-    const char *fn = "vah_attn_bwd_bf16";
     if (B < 0 || H < 1 || N < 0 || ld < H * kHD || ld_out < H * kHD || ld_d < H * kHD || B > 65535 || H > 65535)
         return fail(VAH_E_SHAPE, "%s: bad dims", fn);
     if (B == 0 || N == 0) return VAH_OK;
     if (!q || !k || !v || !out || !dout || !lse || !ws || !dq || !dk || !dv)
         return fail(VAH_E_NULL, "%s: null pointer", fn);
     if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)dout | (uintptr_t)ws) % 16 ||
-        (ld % 8) || (batch_stride % 8) || (ld_out % 8) || (ld_d % 4) || (batch_stride_d % 4) ||
-        ((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 8)
+        (ld % 8) || (ld_out % 8) || (ld_d % 4) || ((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 8)
         return fail(VAH_E_ALIGN, "%s: misaligned operand", fn);
     if (N >= (1 << 24)) return fail(VAH_E_SHAPE, "%s: N too large", fn);
     hipStream_t st = (hipStream_t)stream;
@@ -343,12 +358,12 @@ int vah_attn_bwd_bf16(const void *q, const void *k, const void *v, int64_t ld, i
     const dim3 tg(Np / 64, (unsigned)H, (unsigned)B);
     {
         LaunchScope scope("attn_transpose_bf16", 3 * 2 * B * H * N * kHD * 2, st);
-        hipLaunchKernelGGL(transpose_to_dn, tg, dim3(256), 0, st, (const __bf16 *)k, ld, batch_stride, (int)N, Np, (int)H, kt);
-        hipLaunchKernelGGL(transpose_to_dn, tg, dim3(256), 0, st, (const __bf16 *)q, ld, batch_stride, (int)N, Np, (int)H, qt);
-        hipLaunchKernelGGL(transpose_to_dn, tg, dim3(256), 0, st, (const __bf16 *)dout, ld_out, N * ld_out, (int)N, Np, (int)H, dot);
+        hipLaunchKernelGGL(transpose_to_dn, tg, dim3(256), 0, st, (const __bf16 *)k, ld, rm, (int)N, Np, (int)H, kt);
+        hipLaunchKernelGGL(transpose_to_dn, tg, dim3(256), 0, st, (const __bf16 *)q, ld, rm, (int)N, Np, (int)H, qt);
+        hipLaunchKernelGGL(transpose_to_dn, tg, dim3(256), 0, st, (const __bf16 *)dout, ld_out, rm, (int)N, Np, (int)H, dot);
         const int64_t total = B * H * N;
         hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                           (const __bf16 *)out, (const __bf16 *)dout, ld_out, (int)N, (int)H, total, delta);
+                           (const __bf16 *)out, (const __bf16 *)dout, ld_out, rm, (int)N, (int)H, total, delta);
         if (int rc = check_launch(fn)) return rc;
     }
     const float scale_log2 = scale * 1.4426950408889634f;
@@ -356,15 +371,42 @@ int vah_attn_bwd_bf16(const void *q, const void *k, const void *v, int64_t ld, i
     {
         LaunchScope scope("attn_bwd_dq_bf16", 6 * B * H * N * kHD * 2, st);
         hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, (const __bf16 *)q, (const __bf16 *)k,
-                           (const __bf16 *)v, kt, (const __bf16 *)dout, ld, batch_stride, ld_out, lse, delta,
-                           (int)N, Np, (int)H, scale, scale_log2, (__bf16 *)dq, ld_d, batch_stride_d);
+                           (const __bf16 *)v, kt, (const __bf16 *)dout, ld, rm, ld_out, lse, delta,
+                           (int)N, Np, (int)H, scale, scale_log2, (__bf16 *)dq, ld_d);
         if (int rc = check_launch(fn)) return rc;
     }
     LaunchScope scope("attn_bwd_dkdv_bf16", 8 * B * H * N * kHD * 2, st);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 0, st, (const __bf16 *)q, (const __bf16 *)k,
-                       (const __bf16 *)v, qt, (const __bf16 *)dout, dot, ld, batch_stride, ld_out, lse, delta,
-                       (int)N, Np, (int)H, scale, scale_log2, (__bf16 *)dk, (__bf16 *)dv, ld_d, batch_stride_d);
+                       (const __bf16 *)v, qt, (const __bf16 *)dout, dot, ld, rm, ld_out, lse, delta,
+                       (int)N, Np, (int)H, scale, scale_log2, (__bf16 *)dk, (__bf16 *)dv, ld_d);
     return check_launch(fn);
+}
+
+int vah_attn_bwd_bf16(const void *q, const void *k, const void *v, int64_t ld, int64_t batch_stride,
+                      const void *out, const void *dout, int64_t ld_out, const float *lse, int64_t B,
+                      int64_t H, int64_t N, float scale, void *ws, void *dq, void *dk, void *dv,
+                      int64_t ld_d, int64_t batch_stride_d, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_attn_bwd_bf16";
+    if (N > 0 && (batch_stride != N * ld || batch_stride_d != N * ld_d))
+        return fail(VAH_E_SHAPE, "%s: batch strides must be N*ld", fn);
+    return attn_bwd_impl(fn, q, k, v, ld, attn::RowMap{0, 0, 0, 0, 0}, out, dout, ld_out, lse, B, H, N, scale, ws,
+                         dq, dk, dv, ld_d, stream);
+}
+
+int vah_attn_win_bwd_bf16(const void *q, const void *k, const void *v, int64_t ld, const void *out,
+                          const void *dout, int64_t ld_out, const float *lse, int64_t B, int64_t grid_h,
+                          int64_t grid_w, int64_t win, int64_t H, float scale, void *ws, void *dq,
+                          void *dk, void *dv, int64_t ld_d, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_attn_win_bwd_bf16";
+    attn::RowMap rm;
+    int64_t Z = 0, N = 0;
+    if (win < 1) return fail(VAH_E_SHAPE, "%s: win must be >= 1", fn);
+    if (int rc = attn::make_rowmap(fn, win, B, grid_h, grid_w, &Z, &N, &rm)) return rc;
+    return attn_bwd_impl(fn, q, k, v, ld, rm, out, dout, ld_out, lse, Z, H, N, scale, ws, dq, dk, dv, ld_d, stream);
 }
 
 }  // extern "C"

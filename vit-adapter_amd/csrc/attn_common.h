@@ -60,19 +60,42 @@ __device__ __forceinline__ bf16x8 load_kperm(const __bf16 *row_ptr, int s, int h
     return f;
 }
 
-// (B, N, heads, 64) strided -> (B, heads, 64, Np) dense, zero padded beyond N.
+// Token addressing.  win == 0: sequence z is tokens [z*N, (z+1)*N) of a (B*N, ...) row-major tensor.
+// win > 0: sequence z = (image b, window wy, wx) of a (B, H, W) token grid cut into win x win windows
+// (grid padded up to a multiple of win); local token i = ly*win + lx maps to pixel (wy*win+ly,
+// wx*win+lx), or to NO row (-1) when that pixel lies in the padding: such tokens read as zero rows
+// (the reference zero-pads q, k, v AFTER the projection, base/vit.py:143-145) and are never stored.
+struct RowMap {
+    int win, H, W, nwx, nwin;
+};
+__device__ __forceinline__ int64_t grow(const RowMap &rm, int z, int i, int N) {
+    if (rm.win == 0) return (int64_t)z * N + i;
+    const int b = z / rm.nwin, w = z - b * rm.nwin;
+    const int wy = w / rm.nwx, wx = w - wy * rm.nwx;
+    const int ly = i / rm.win, lx = i - ly * rm.win;
+    const int y = wy * rm.win + ly, x = wx * rm.win + lx;
+    if (y >= rm.H || x >= rm.W) return -1;
+    return ((int64_t)b * rm.H + y) * rm.W + x;
+}
+
+// host: window geometry -> RowMap, number of sequences Z and tokens per sequence N (attn_fwd.hip)
+int make_rowmap(const char *fn, int64_t win, int64_t B, int64_t gh, int64_t gw, int64_t *Z, int64_t *N,
+                RowMap *rm);
+
+// (rows, heads, 64) strided -> (Z, heads, 64, Np) dense, zero padded beyond N / outside the image.
 static __global__ __launch_bounds__(256) void transpose_to_dn(const __bf16 *__restrict__ src, int64_t ld,
-                                                              int64_t batch_stride, int N, int Np, int H,
+                                                              RowMap rm, int N, int Np, int H,
                                                               __bf16 *__restrict__ dst) {
     __shared__ __attribute__((aligned(16))) __bf16 tile[64 * kPadRow];
     const int n0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
-    const __bf16 *s = src + b * batch_stride + (int64_t)h * kHD;
+    const __bf16 *s = src + (int64_t)h * kHD;
     for (int c = threadIdx.x; c < 512; c += 256) {
         const int row = c >> 3, col = (c & 7) * 8;
         bf16x8 v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
-        if (n0 + row < N) v = *reinterpret_cast<const bf16x8 *>(s + (int64_t)(n0 + row) * ld + col);
+        const int64_t gr = n0 + row < N ? grow(rm, b, n0 + row, N) : -1;
+        if (gr >= 0) v = *reinterpret_cast<const bf16x8 *>(s + gr * ld + col);
         *reinterpret_cast<bf16x8 *>(tile + row * kPadRow + col) = v;
     }
     __syncthreads();

@@ -31,7 +31,7 @@ constexpr int kKTile = 64;               // keys per step
 
 __global__ __launch_bounds__(256) void attn_fwd_kernel(
     const __bf16 *__restrict__ q, const __bf16 *__restrict__ k, const __bf16 *__restrict__ vt,
-    int64_t ld, int64_t batch_stride, int N, int Np, int H, float scale_log2,
+    int64_t ld, RowMap rm, int N, int Np, int H, float scale_log2,
     __bf16 *__restrict__ out, int64_t ld_out, float *__restrict__ lse) {
     // double buffered: tile t+1 is written while tile t is being multiplied (one barrier per tile)
     __shared__ __attribute__((aligned(16))) __bf16 s_k2[2][kKTile * kPadRow];
@@ -43,14 +43,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
     const int qrow = blockIdx.x * kQBlock + wave * 32 + r;           // this lane's query
     const int qload = min(qrow, N - 1);
 
-    const __bf16 *qb = q + b * batch_stride + (int64_t)h * kHD;
-    const __bf16 *kb = k + b * batch_stride + (int64_t)h * kHD;
+    const __bf16 *qb = q + (int64_t)h * kHD;
+    const __bf16 *kb = k + (int64_t)h * kHD;
     const __bf16 *vtb = vt + ((int64_t)(b * H + h) * kHD) * Np;
+    const int64_t gq = grow(rm, b, qload, N);          // -1: padded token, q = 0
 
     bf16x8 qf[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-        qf[kk] = *reinterpret_cast<const bf16x8 *>(qb + (int64_t)qload * ld + 16 * kk + 8 * hf);
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[kk][j] = (__bf16)0.f;
+        if (gq >= 0) qf[kk] = *reinterpret_cast<const bf16x8 *>(qb + gq * ld + 16 * kk + 8 * hf);
+    }
 
     f32x16 o[2] = {zero16(), zero16()};
     float m_run = -INFINITY, l_run = 0.f;
@@ -62,8 +66,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
     auto fetch = [&](int key0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) pk0[j] = pk1[j] = (__bf16)0.f;
-        if (key0 + kr0 < N) pk0 = *reinterpret_cast<const bf16x8 *>(kb + (int64_t)(key0 + kr0) * ld + kc0);
-        if (key0 + kr1 < N) pk1 = *reinterpret_cast<const bf16x8 *>(kb + (int64_t)(key0 + kr1) * ld + kc1);
+        const int64_t g0 = key0 + kr0 < N ? grow(rm, b, key0 + kr0, N) : -1;
+        const int64_t g1 = key0 + kr1 < N ? grow(rm, b, key0 + kr1, N) : -1;
+        if (g0 >= 0) pk0 = *reinterpret_cast<const bf16x8 *>(kb + g0 * ld + kc0);
+        if (g1 >= 0) pk1 = *reinterpret_cast<const bf16x8 *>(kb + g1 * ld + kc1);
         pv0 = *reinterpret_cast<const bf16x8 *>(vtb + (int64_t)kr0 * Np + key0 + kc0);
         pv1 = *reinterpret_cast<const bf16x8 *>(vtb + (int64_t)kr1 * Np + key0 + kc1);
     };
@@ -148,8 +154,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
-    if (qrow < N) {
-        __bf16 *op = out + ((int64_t)b * N + qrow) * ld_out + (int64_t)h * kHD;
+    if (qrow < N && gq >= 0) {
+        __bf16 *op = out + gq * ld_out + (int64_t)h * kHD;
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -160,6 +166,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(
                 *reinterpret_cast<bf16x4 *>(op + db * 32 + 8 * g + 4 * hf) = w;
             }
         if (hf == 0) lse[((int64_t)b * H + h) * N + qrow] = m_run + log2f(l_tot);
+    } else if (qrow < N && hf == 0) {
+        lse[((int64_t)b * H + h) * N + qrow] = INFINITY;     // padded query: p = 0 in the backward
     }
 }
 
@@ -171,19 +179,68 @@ extern "C" {
 
 int64_t vah_attn_padded_len(int64_t N) { return (N + 63) / 64 * 64; }
 
+}  // extern "C"
+
+namespace vah {
+namespace attn {
+// Shared argument handling of the plain and the windowed entry points: Z sequences of N tokens.
+int make_rowmap(const char *fn, int64_t win, int64_t B, int64_t gh, int64_t gw, int64_t *Z, int64_t *N,
+                RowMap *rm) {
+    if (win == 0) {
+        *rm = RowMap{0, 0, 0, 0, 0};
+        return VAH_OK;
+    }
+    if (win < 1 || win > 64 || gh < 1 || gw < 1 || B < 0)
+        return fail(VAH_E_SHAPE, "%s: bad window geometry", fn);
+    const int64_t nwy = (gh + win - 1) / win, nwx = (gw + win - 1) / win;
+    *rm = RowMap{(int)win, (int)gh, (int)gw, (int)nwx, (int)(nwx * nwy)};
+    *Z = B * nwx * nwy;
+    *N = win * win;
+    return VAH_OK;
+}
+}  // namespace attn
+}  // namespace vah
+
+extern "C" {
+
+static int attn_fwd_impl(const char *fn, const void *q, const void *k, const void *v, int64_t ld,
+                         vah::attn::RowMap rm, int64_t B, int64_t H, int64_t N, float scale,
+                         void *vt_ws, void *out, int64_t ld_out, float *lse, void *stream);
+
 int vah_attn_fwd_bf16(const void *q, const void *k, const void *v, int64_t ld, int64_t batch_stride,
                       int64_t B, int64_t H, int64_t N, float scale, void *vt_ws, void *out,
                       int64_t ld_out, float *lse, void *stream) {
     using namespace vah;
-    using namespace vah::attn;
     clear_error();
     const char *fn = "vah_attn_fwd_bf16";
+    if (N > 0 && batch_stride != N * ld) return fail(VAH_E_SHAPE, "%s: batch_stride must be N*ld", fn);
+    return attn_fwd_impl(fn, q, k, v, ld, attn::RowMap{0, 0, 0, 0, 0}, B, H, N, scale, vt_ws, out, ld_out, lse, stream);
+}
+
+int vah_attn_win_fwd_bf16(const void *q, const void *k, const void *v, int64_t ld, int64_t B,
+                          int64_t grid_h, int64_t grid_w, int64_t win, int64_t H, float scale,
+                          void *vt_ws, void *out, int64_t ld_out, float *lse, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_attn_win_fwd_bf16";
+    attn::RowMap rm;
+    int64_t Z = 0, N = 0;
+    if (win < 1) return fail(VAH_E_SHAPE, "%s: win must be >= 1", fn);
+    if (int rc = attn::make_rowmap(fn, win, B, grid_h, grid_w, &Z, &N, &rm)) return rc;
+    return attn_fwd_impl(fn, q, k, v, ld, rm, Z, H, N, scale, vt_ws, out, ld_out, lse, stream);
+}
+
+static int attn_fwd_impl(const char *fn, const void *q, const void *k, const void *v, int64_t ld,
+                         vah::attn::RowMap rm, int64_t B, int64_t H, int64_t N, float scale,
+                         void *vt_ws, void *out, int64_t ld_out, float *lse, void *stream) {
+    using namespace vah;
+    using namespace vah::attn;
     if (B < 0 || H < 1 || N < 0 || ld < H * kHD || ld_out < H * kHD || B > 65535 || H > 65535)
         return fail(VAH_E_SHAPE, "%s: bad dims B=%lld H=%lld N=%lld ld=%lld", fn, (long long)B,
                     (long long)H, (long long)N, (long long)ld);
     if (B == 0 || N == 0) return VAH_OK;
     if (!q || !k || !v || !vt_ws || !out || !lse) return fail(VAH_E_NULL, "%s: null pointer", fn);
-    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)vt_ws) % 16 || (ld % 8) || (batch_stride % 8) ||
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)vt_ws) % 16 || (ld % 8) ||
         ((uintptr_t)out % 8) || (ld_out % 4))
         return fail(VAH_E_ALIGN, "%s: q/k/v need 16-byte aligned rows (ld %% 8 == 0), out 8-byte", fn);
     if (N >= (1 << 24)) return fail(VAH_E_SHAPE, "%s: N too large", fn);
@@ -192,7 +249,7 @@ int vah_attn_fwd_bf16(const void *q, const void *k, const void *v, int64_t ld, i
     {
         LaunchScope scope("attn_transpose_bf16", 2 * B * H * N * kHD * 2, st);
         hipLaunchKernelGGL(transpose_to_dn, dim3(Np / 64, (unsigned)H, (unsigned)B), dim3(256), 0, st,
-                           (const __bf16 *)v, ld, batch_stride, (int)N, Np, (int)H, (__bf16 *)vt_ws);
+                           (const __bf16 *)v, ld, rm, (int)N, Np, (int)H, (__bf16 *)vt_ws);
         if (int rc = check_launch(fn)) return rc;
     }
     const float scale_log2 = scale * 1.4426950408889634f;
@@ -200,7 +257,7 @@ int vah_attn_fwd_bf16(const void *q, const void *k, const void *v, int64_t ld, i
     LaunchScope scope("attn_fwd_bf16", 4 * B * H * N * kHD * 2 + B * H * N * 4, st);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)((N + kQBlock - 1) / kQBlock), (unsigned)H, (unsigned)B),
                        dim3(256), 0, st, (const __bf16 *)q, (const __bf16 *)k, (const __bf16 *)vt_ws, ld,
-                       batch_stride, (int)N, Np, (int)H, scale_log2, (__bf16 *)out, ld_out, lse);
+                       rm, (int)N, Np, (int)H, scale_log2, (__bf16 *)out, ld_out, lse);
     return check_launch(fn);
 }
 

@@ -119,7 +119,13 @@ class WindowedAttention(nn.Module):
         ws = self.window_size
         Hp, Wp = math.ceil(H / ws) * ws, math.ceil(W / ws) * ws
         nh, nw = Hp // ws, Wp // ws
-        qkv = self.qkv(x).view(B, H, W, 3 * C)
+        qkv = self.qkv(x)
+        if self.pad_mode == 'constant':
+            fused = kernels.window_attention(qkv.view(B, N, 3, self.num_heads, C // self.num_heads),
+                                             self.scale, H, W, ws, self.attn_drop.p if self.training else 0.)
+            if fused is not None:      # windows cut inside the kernels: no pad / partition copies
+                return self.proj_drop(self.proj(fused.reshape(B, N, C)))
+        qkv = qkv.view(B, H, W, 3 * C)
         if Hp != H or Wp != W:
             if self.pad_mode == 'constant':
                 qkv = F.pad(qkv, (0, 0, 0, Wp - W, 0, Hp - H))         # zeros AFTER the projection

@@ -69,6 +69,60 @@ def _attention_backward(qkv, out, lse, dout, scale):
     return dqkv
 
 
+class _WindowFlashAttention(torch.autograd.Function):
+    """bf16 MFMA attention inside win x win windows of a (B, gh, gw) token grid, windows cut by the
+    kernels' addressing (no pad / partition / merge / crop copies)."""
+
+    @staticmethod
+    def forward(ctx, qkv, scale, gh, gw, win):
+        B, N, three, H, hd = qkv.shape
+        qkv = qkv.contiguous()
+        C = H * hd
+        Z = B * (-(-gh // win)) * (-(-gw // win))
+        Nw = win * win
+        out = torch.empty((B, N, H, hd), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((Z, H, Nw), dtype=torch.float32, device=qkv.device)
+        ws = torch.empty((Z * H * hd * _vah.lib.vah_attn_padded_len(Nw),), dtype=qkv.dtype, device=qkv.device)
+        base, esz = qkv.data_ptr(), qkv.element_size()
+        with torch.cuda.device(qkv.device):
+            rc = _vah.lib.vah_attn_win_fwd_bf16(base, base + C * esz, base + 2 * C * esz, 3 * C, B, gh, gw,
+                                                win, H, float(scale), ws.data_ptr(), out.data_ptr(), C,
+                                                lse.data_ptr(), _stream(qkv))
+        _vah.check(rc, 'vah_attn_win_fwd_bf16')
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.cfg = (float(scale), gh, gw, win, Z, Nw)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        scale, gh, gw, win, Z, Nw = ctx.cfg
+        B, N, _, H, hd = qkv.shape
+        C = H * hd
+        dout = dout.contiguous().to(qkv.dtype)
+        dqkv = torch.empty_like(qkv)
+        ws = torch.empty((_vah.lib.vah_attn_bwd_workspace_bytes(Z, H, Nw),), dtype=torch.uint8, device=qkv.device)
+        base, dbase, esz = qkv.data_ptr(), dqkv.data_ptr(), qkv.element_size()
+        with torch.cuda.device(qkv.device):
+            rc = _vah.lib.vah_attn_win_bwd_bf16(
+                base, base + C * esz, base + 2 * C * esz, 3 * C, out.data_ptr(), dout.data_ptr(), C,
+                lse.data_ptr(), B, gh, gw, win, H, scale, ws.data_ptr(), dbase, dbase + C * esz,
+                dbase + 2 * C * esz, 3 * C, _stream(qkv))
+        _vah.check(rc, 'vah_attn_win_bwd_bf16')
+        return dqkv, None, None, None, None
+
+
+def window_attention(qkv, scale, gh, gw, win, dropout_p=0.):
+    """Windowed attention on the packed projection of a (B, gh*gw) token grid; returns
+    (B, gh*gw, heads, head_dim) or None when the fused path does not apply (the caller then uses
+    the reference's pad / partition sequence)."""
+    if (qkv.is_cuda and qkv.dtype == torch.bfloat16 and qkv.shape[-1] == 64 and dropout_p == 0.
+            and qkv.shape[1] == gh * gw and qkv.numel() > 0 and 1 <= win <= 64
+            and not FLAGS['force_math_attention'] and FLAGS['fused_windows']):
+        return _WindowFlashAttention.apply(qkv, scale, gh, gw, win)
+    return None
+
+
 def attention(qkv, scale, dropout_p=0.):
     """Softmax attention on a packed projection.
 
@@ -83,4 +137,4 @@ def attention(qkv, scale, dropout_p=0.):
     return _attention_math(qkv, scale, dropout_p)
 
 
-FLAGS = {'force_math_attention': False}
+FLAGS = {'force_math_attention': False, 'fused_windows': True}
