@@ -140,6 +140,16 @@ int vah_msda_backward_win_f32(const float *value, const int64_t *shapes, const i
  * Supported: D == 32 and (L, P) in {(1,4), (3,4), (4,4)}  (vah_msda_fused_supported).
  * Backward: grad_value fp32 (N,S,M,32) zero on entry (float atomics); d_offsets / d_logits in
  * param_dtype, fully written.
+ *
+ * Optional PULL SCHEDULE for grad_value (tile_meta != NULL): the value maps are cut into tiles of
+ * at most 256 pixels; tile_meta holds 8 int32 per tile {level, y0, x0, ny, nx, cand_start,
+ * cand_count, 0} and cand the concatenated candidate query lists.  Tile t's candidates MUST include
+ * every query whose reference point, in pixels of the tile's level, lies within near_radius + 2 of
+ * the tile rectangle (any superset is fine).  Samples whose offset is within near_radius pixels in
+ * both axes are then accumulated per tile in LDS buckets and flushed with one atomic per pixel row;
+ * the others are scattered with per-sample atomics as without a schedule.  cap_entries = capacity of
+ * the per-workgroup bucket store (8 bytes each, <= 150 KiB); overflow falls back to atomics.  The
+ * result is the same gradient (fp32 summation order aside) for any valid schedule.
  * ------------------------------------------------------------------------------------ */
 int vah_msda_fused_supported(int64_t D, int64_t L, int64_t P);
 int vah_msda_fused_forward(const void *value, int value_dtype, const int64_t *shapes, const int64_t *lsi,
@@ -151,7 +161,9 @@ int vah_msda_fused_backward(const void *value, int value_dtype, const int64_t *s
                             const void *offsets, const void *logits, int param_dtype,
                             const float *ref, int64_t ref_levels, const void *grad_out,
                             int64_t N, int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P,
-                            float *grad_value, void *d_offsets, void *d_logits, void *stream);
+                            float *grad_value, void *d_offsets, void *d_logits,
+                            const int32_t *tile_meta, const int32_t *cand, int64_t ntiles,
+                            float near_radius, int64_t cap_entries, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Softmax attention of the ViT blocks, bf16, head_dim 64  

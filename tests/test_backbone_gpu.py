@@ -228,3 +228,44 @@ def test_fused_core_bf16_autocast_matches_unfused(monkeypatch, L, shapes, qshape
     for a, b, nm in zip(res[0], res[1], ('out', 'dquery', 'dfeat', 'd offsets.w', 'd attn.b', 'd value.w')):
         err = (a - b).abs().max().item()
         assert err <= 4e-2 * max(1.0, b.abs().max().item()), (nm, err)
+
+
+@pytest.mark.parametrize('L,shapes,qshapes,scale', [
+    (3, [(32, 32), (16, 16), (8, 8)], [(16, 16)], 1.0),
+    (1, [(16, 16)], [(32, 32), (16, 16), (8, 8)], 1.0),
+    (1, [(16, 24)], [(32, 48), (16, 24), (8, 12)], 4.0),        # many far samples (|offset| > radius)
+])
+def test_fused_backward_pull_schedule_equals_atomics(monkeypatch, L, shapes, qshapes, scale):
+    """grad_value through the tile/bucket ("pull") pass == grad_value through per-sample atomics,
+    including samples beyond the near radius and a bucket store that overflows."""
+    from ops.functions import MSDeformAttnFusedFunction
+    from ops.functions import ms_deform_attn_fused as mf
+    torch.manual_seed(11)
+    N, M, D, P = 2, 6, 32, 4
+    S, Lq = sum(h * w for h, w in shapes), sum(h * w for h, w in qshapes)
+    value = torch.randn(N, S, M, D, device='cuda')
+    off = (cases.ring_offsets(M, L, P).cuda()[None, None] + torch.randn(N, Lq, M, L, P, 2, device='cuda')) * scale
+    logit = torch.randn(N, Lq, M, L * P, device='cuda')
+    ref = cases.reference_grid(qshapes).cuda()
+    hw = torch.as_tensor(shapes, dtype=torch.long, device='cuda')
+    lsi = cases.level_start_index(shapes).cuda()
+    gout = torch.randn(N, Lq, M * D, device='cuda')
+    res = {}
+    for tag, env in (('atomics', {'VAH_MSDA_PULL': '0'}), ('pull', {'VAH_MSDA_PULL': '1'}),
+                     ('pull_overflow', {'VAH_MSDA_PULL': '1', 'VAH_MSDA_PULL_CAP': '64'}),
+                     ('pull_r2', {'VAH_MSDA_PULL': '1', 'VAH_MSDA_PULL_RADIUS': '2.0', 'VAH_MSDA_PULL_TILE': '5'})):
+        for k in ('VAH_MSDA_PULL', 'VAH_MSDA_PULL_CAP', 'VAH_MSDA_PULL_RADIUS', 'VAH_MSDA_PULL_TILE'):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        mf._PULL_CACHE.clear()
+        v, o, lg = [t.clone().requires_grad_(True) for t in (value, off, logit)]
+        out = MSDeformAttnFusedFunction.apply(v, hw, lsi, o, lg, ref)
+        out.backward(gout)
+        res[tag] = (out.detach(), v.grad, o.grad, lg.grad)
+    mf._PULL_CACHE.clear()
+    base = res['atomics']
+    for tag in ('pull', 'pull_overflow', 'pull_r2'):
+        for a, b, nm in zip(res[tag], base, ('out', 'grad_value', 'd_off', 'd_logit')):
+            err = (a - b).abs().max().item()
+            assert err <= 1e-4 * max(1.0, b.abs().max().item()), (tag, nm, err)

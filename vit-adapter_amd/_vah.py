@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -66,7 +66,8 @@ lib.vah_msda_fused_supported.argtypes = [_i64, _i64, _i64]
 lib.vah_msda_fused_supported.restype = ctypes.c_int
 lib.vah_msda_fused_forward.argtypes = [_p, _ci, _p, _p, _p, _p, _ci, _p, _i64] + [_i64] * 7 + [_p, _p]
 lib.vah_msda_fused_forward.restype = ctypes.c_int
-lib.vah_msda_fused_backward.argtypes = [_p, _ci, _p, _p, _p, _p, _ci, _p, _i64, _p] + [_i64] * 7 + [_p] * 4
+lib.vah_msda_fused_backward.argtypes = ([_p, _ci, _p, _p, _p, _p, _ci, _p, _i64, _p] + [_i64] * 7 + [_p] * 3
+                                        + [_p, _p, _i64, ctypes.c_float, _i64, _p])
 lib.vah_msda_fused_backward.restype = ctypes.c_int
 _f = ctypes.c_float
 lib.vah_layernorm_fwd_f32_bf16.argtypes = [_p, _p, _p, _i64, _i64, _f, _p, _p, _p, _p]

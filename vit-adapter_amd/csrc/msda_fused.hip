@@ -144,12 +144,16 @@ __global__ __launch_bounds__(kBlock) void msda_fused_fwd(
 // backward: one lane per channel (32 lanes per row); grad_value accumulated in fp32 with
 // global_atomic_add_f32 on whole 128-byte rows; d(offsets), d(logits) written in PT
 // ---------------------------------------------------------------------------------------
+// near_radius >= 0 selects the SPLIT mode: samples whose offset is within near_radius pixels (of
+// their level) in both axes leave grad_value to msda_fused_bwd_gv below; only the rare "far" samples
+// are scattered with atomics here.  near_radius < 0: every sample is scattered here.
 template <typename VT, typename PT, int L, int P>
 __global__ __launch_bounds__(kBlock) void msda_fused_bwd(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const PT *__restrict__ off, const PT *__restrict__ logit, const float *__restrict__ ref,
     int ref_levels, const VT *__restrict__ grad_out, int64_t S, int M, int64_t Lq, int64_t total_rows,
-    int64_t nblocks, float *__restrict__ grad_value, PT *__restrict__ d_off, PT *__restrict__ d_logit) {
+    int64_t nblocks, float near_radius, float *__restrict__ grad_value, PT *__restrict__ d_off,
+    PT *__restrict__ d_logit) {
     constexpr int LP = L * P;
     constexpr int ROWS = kBlock / kD;
     const int64_t blk = xcd_chunked_block(nblocks);
@@ -175,9 +179,11 @@ __global__ __launch_bounds__(kBlock) void msda_fused_bwd(
         float *gvl = grad_value + head_off + lv.start * stride;
         Tap<float> t[P];
         float v[P][4];
+        bool scatter[P];
 #pragma unroll
         for (int u = 0; u < P; ++u) {
             const float2 o = load2(op + 2 * (l * P + u));
+            scatter[u] = !(fabsf(o.x) <= near_radius && fabsf(o.y) <= near_radius);
             // an invalid level gates every sample off (W = H = 0 would not): use a location that fails
             t[u] = make_tap<float>(lv.valid ? rp.x + o.x / (float)lv.W : -8.f,
                                    lv.valid ? rp.y + o.y / (float)lv.H : -8.f, max(lv.H, 1), max(lv.W, 1));
@@ -193,7 +199,8 @@ __global__ __launch_bounds__(kBlock) void msda_fused_bwd(
             const float tv = g * p[s];
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (lv.valid && t[u].ok[k]) atomicAdd(gvl + (int64_t)t[u].row[k] * stride, t[u].cw[k] * tv);
+                if (scatter[u] && lv.valid && t[u].ok[k])
+                    atomicAdd(gvl + (int64_t)t[u].row[k] * stride, t[u].cw[k] * tv);
             const float gh = t[u].hw * (v[u][2] - v[u][0]) + t[u].lw * (v[u][3] - v[u][1]);
             const float gw = t[u].hh * (v[u][1] - v[u][0]) + t[u].lh * (v[u][3] - v[u][2]);
             const float val = t[u].cw[0] * v[u][0] + t[u].cw[1] * v[u][1] + t[u].cw[2] * v[u][2] +
@@ -216,6 +223,287 @@ __global__ __launch_bounds__(kBlock) void msda_fused_bwd(
         }
 }
 
+// Split-mode variant of the backward above: 8 lanes x 4 channels per row (16-byte corner loads as
+// in the forward: 4x fewer gather instructions than one channel per lane).  It only makes sense when
+// almost no sample scatters here (the far ones do, with 4 strided atomics per lane), i.e. together
+// with msda_fused_bwd_gv.
+__device__ __forceinline__ float sum8(float x) {
+    x += dpp_mov<0xB1, 0xF>(x);     // quad_perm [1,0,3,2]
+    x += dpp_mov<0x4E, 0xF>(x);     // quad_perm [2,3,0,1]
+    x += dpp_mov<0x141, 0xF>(x);    // row_half_mirror: lanes 0-7 <-> 7-0 within each 8
+    return x;                       // every lane of the 8-lane group holds the sum
+}
+
+template <typename VT, typename PT, int L, int P>
+__global__ __launch_bounds__(kBlock) void msda_fused_bwd_vec4(
+    const VT *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
+    const PT *__restrict__ off, const PT *__restrict__ logit, const float *__restrict__ ref,
+    int ref_levels, const VT *__restrict__ grad_out, int64_t S, int M, int64_t Lq, int64_t total_rows,
+    int64_t nblocks, float near_radius, float *__restrict__ grad_value, PT *__restrict__ d_off,
+    PT *__restrict__ d_logit) {
+    constexpr int LP = L * P;
+    constexpr int ROWS = kBlock / 8;
+    const int64_t blk = xcd_chunked_block(nblocks);
+    if (blk >= nblocks) return;
+    const int sub = threadIdx.x & 7;
+    const int64_t work = blk * ROWS + (threadIdx.x >> 3);
+    if (work >= total_rows) return;          // whole 8-lane groups leave together
+    const int64_t q = work % Lq;
+    const int m = (int)((work / Lq) % M);
+    const int64_t n = work / Lq / M;
+    const int64_t row = (n * Lq + q) * M + m;
+    const int64_t stride = (int64_t)M * kD;
+    const int64_t head_off = n * S * stride + m * kD + sub * 4;
+
+    float p[LP], ga[LP], gx[LP], gy[LP];
+    row_softmax<PT, LP>(logit + row * LP, p);
+    const PT *op = off + row * LP * 2;
+    const float4 g = load4(grad_out + row * kD + sub * 4);
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const Level lv = read_level(shapes, lsi, l, S);
+        const float2 rp = *reinterpret_cast<const float2 *>(ref + (q * ref_levels + (ref_levels > 1 ? l : 0)) * 2);
+        const VT *vl = value + head_off + lv.start * stride;
+        float *gvl = grad_value + head_off + lv.start * stride;
+        Tap<float> t[P];
+        float4 v[P][4];
+        bool scatter[P];
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            const float2 o = load2(op + 2 * (l * P + u));
+            scatter[u] = !(fabsf(o.x) <= near_radius && fabsf(o.y) <= near_radius);
+            t[u] = make_tap<float>(lv.valid ? rp.x + o.x / (float)lv.W : -8.f,
+                                   lv.valid ? rp.y + o.y / (float)lv.H : -8.f, max(lv.H, 1), max(lv.W, 1));
+        }
+#pragma unroll
+        for (int u = 0; u < P; ++u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (lv.valid && t[u].ok[k]) v[u][k] = load4(vl + (int64_t)t[u].row[k] * stride);
+            }
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            const int s = l * P + u;
+            const float a = p[s];
+            if (scatter[u] && lv.valid) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (t[u].ok[k]) {
+                        float *d = gvl + (int64_t)t[u].row[k] * stride;
+                        const float w = t[u].cw[k] * a;
+                        atomicAdd(d + 0, w * g.x);
+                        atomicAdd(d + 1, w * g.y);
+                        atomicAdd(d + 2, w * g.z);
+                        atomicAdd(d + 3, w * g.w);
+                    }
+            }
+            // per-lane partial dot products over its 4 channels
+            auto dot4 = [&](const float4 &x) { return g.x * x.x + g.y * x.y + g.z * x.z + g.w * x.w; };
+            const float d0 = dot4(v[u][0]), d1 = dot4(v[u][1]), d2 = dot4(v[u][2]), d3 = dot4(v[u][3]);
+            const float val = t[u].cw[0] * d0 + t[u].cw[1] * d1 + t[u].cw[2] * d2 + t[u].cw[3] * d3;
+            const float gh = t[u].hw * (d2 - d0) + t[u].lw * (d3 - d1);
+            const float gw = t[u].hh * (d1 - d0) + t[u].lh * (d3 - d2);
+            ga[s] = sum8(val);
+            gx[s] = sum8(gw * a);
+            gy[s] = sum8(gh * a);
+        }
+    }
+    float dot = 0.f;
+#pragma unroll
+    for (int s = 0; s < LP; ++s) dot += p[s] * ga[s];
+    // LP <= 16 samples, 8 lanes: lane `sub` stores samples sub and sub + 8
+#pragma unroll
+    for (int s = 0; s < LP; ++s)
+        if ((s & 7) == sub) {
+            d_logit[row * LP + s] = (PT)(p[s] * (ga[s] - dot));
+            store2(d_off + (row * LP + s) * 2, gx[s], gy[s]);
+        }
+}
+
+// ---------------------------------------------------------------------------------------
+// grad_value of the NEAR samples without per-sample atomics ("pull" form).
+//
+// The value maps are cut into tiles; a workgroup owns (batch n, head m, one tile of one level) and
+// is given, by the host, the list of CANDIDATE queries whose reference point lies within
+// near_radius (+ margin) of the tile - a static function of the reference grid, built once per
+// geometry.  It recomputes the candidates' sampling taps, keeps the (sample, corner) pairs that land
+// inside its tile, buckets them by pixel with an LDS counting sort (integer LDS atomics on the
+// bucket counters only), and then one half-wave per pixel sums  w * grad_out[row]  over the pixel's
+// bucket in registers (32 channel lanes) and issues ONE 128-byte atomic add per pixel row.  Every
+// near (sample, corner) pair is found by exactly one workgroup (tiles partition the level), far
+// samples were scattered by msda_fused_bwd: together they are the whole gradient.
+// Replaces 4 x 128 B of memory-side float atomics per sample (the 1.2 TB/s atomic roofline the plain
+// backward sits on) with one per pixel row and tile.
+// ---------------------------------------------------------------------------------------
+struct TileMeta {          // 8 x int32 per tile (host built)
+    int level, y0, x0, ny, nx, cand_start, cand_count, pad;
+};
+constexpr int kMaxTilePx = 256;
+constexpr int kGvThreads = 1024;     // 32 half-waves: enough 128-byte row gathers in flight per CU
+
+template <typename PT, int LP>
+__device__ __forceinline__ float softmax_weight(const PT *__restrict__ lg, int s) {
+    float p[LP];
+    row_softmax<PT, LP>(lg, p);
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) r = (i == s) ? p[i] : r;
+    return r;
+}
+
+template <typename VT, typename PT, int L, int P>
+__global__ __launch_bounds__(kGvThreads) void msda_fused_bwd_gv(
+    const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi, const PT *__restrict__ off,
+    const PT *__restrict__ logit, const float *__restrict__ ref, int ref_levels,
+    const VT *__restrict__ grad_out, const int *__restrict__ tile_meta, const int *__restrict__ cand,
+    int ntiles, int64_t S, int M, int64_t Lq, float near_radius, int cap, float *__restrict__ grad_value) {
+    constexpr int LP = L * P;
+    extern __shared__ __attribute__((aligned(16))) int s_entries[];        // cap x {row, weight bits}
+    __shared__ int s_cnt[kMaxTilePx], s_start[kMaxTilePx + 1], s_cur[kMaxTilePx];
+
+    const int64_t b = blockIdx.x;
+    const int tile = (int)(b % ntiles);
+    const int m = (int)((b / ntiles) % M);
+    const int64_t n = b / ntiles / M;
+    const TileMeta tm = reinterpret_cast<const TileMeta *>(tile_meta)[tile];
+    const int l = tm.level;
+    const Level lv = read_level(shapes, lsi, l, S);
+    const int npx = tm.ny * tm.nx;
+    if (!lv.valid || npx <= 0 || npx > kMaxTilePx || tm.cand_count <= 0) return;
+
+    for (int i = threadIdx.x; i < npx; i += kGvThreads) s_cnt[i] = s_cur[i] = 0;
+    __syncthreads();
+
+    const int nitems = tm.cand_count * P;
+    float *gv_level = grad_value + (n * S + lv.start) * (int64_t)M * kD + (int64_t)m * kD;
+    // One lane per (candidate query, point), IB items per lane in flight: the three dependent global
+    // reads of an item (candidate index -> offset / reference point -> logits) are issued for the
+    // whole batch before anything is consumed.  PASS 0 counts the bucket sizes, PASS 1 fills them.
+    constexpr int IB = 4;
+    auto pass = [&](const int which) {
+        for (int base = threadIdx.x; base < nitems; base += kGvThreads * IB) {
+            int64_t qv[IB], rowv[IB];
+            float2 ov[IB], rpv[IB];
+            bool live[IB];
+            int pv[IB];
+#pragma unroll
+            for (int u = 0; u < IB; ++u) {
+                const int item = base + u * kGvThreads;
+                live[u] = item < nitems;
+                const int ci = live[u] ? item / P : 0;
+                pv[u] = live[u] ? item - ci * P : 0;
+                qv[u] = cand[tm.cand_start + ci];
+                live[u] = live[u] && qv[u] >= 0 && qv[u] < Lq;
+                if (!live[u]) qv[u] = 0;
+            }
+#pragma unroll
+            for (int u = 0; u < IB; ++u) {
+                rowv[u] = (n * Lq + qv[u]) * M + m;
+                ov[u] = load2(off + (rowv[u] * LP + l * P + pv[u]) * 2);
+                rpv[u] = *reinterpret_cast<const float2 *>(ref + (qv[u] * ref_levels + (ref_levels > 1 ? l : 0)) * 2);
+            }
+#pragma unroll
+            for (int u = 0; u < IB; ++u) {
+                if (!live[u]) continue;
+                if (!(fabsf(ov[u].x) <= near_radius && fabsf(ov[u].y) <= near_radius)) continue;   // far: kernel A
+                const Tap<float> t = make_tap<float>(rpv[u].x + ov[u].x / (float)lv.W,
+                                                     rpv[u].y + ov[u].y / (float)lv.H, lv.H, lv.W);
+                int px[4];
+                bool any = false;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    px[k] = -1;
+                    if (!t.ok[k]) continue;
+                    const int y = t.row[k] / lv.W, x = t.row[k] - y * lv.W;
+                    const int ry = y - tm.y0, rx = x - tm.x0;
+                    if (ry < 0 || ry >= tm.ny || rx < 0 || rx >= tm.nx) continue;
+                    px[k] = ry * tm.nx + rx;
+                    any = true;
+                }
+                if (!any) continue;
+                if (which == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (px[k] >= 0) atomicAdd(&s_cnt[px[k]], 1);
+                    continue;
+                }
+                const float a = softmax_weight<PT, LP>(logit + rowv[u] * LP, l * P + pv[u]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (px[k] < 0) continue;
+                    const float w = t.cw[k] * a;
+                    const int slot = s_start[px[k]] + atomicAdd(&s_cur[px[k]], 1);
+                    if (slot < cap) {
+                        s_entries[2 * slot] = (int)rowv[u];
+                        s_entries[2 * slot + 1] = __float_as_int(w);
+                    } else {       // bucket store full: scatter directly (correct, just slow)
+                        const int y = tm.y0 + px[k] / tm.nx, x = tm.x0 + px[k] % tm.nx;
+                        float *dst = gv_level + ((int64_t)y * lv.W + x) * (int64_t)M * kD;
+                        for (int c = 0; c < kD; ++c) atomicAdd(dst + c, w * (float)grad_out[rowv[u] * kD + c]);
+                    }
+                }
+            }
+        }
+    };
+
+    pass(0);
+    __syncthreads();
+    // exclusive scan of the bucket sizes (<= 256 buckets): one wave, 4 buckets per lane
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int v[4], sum = 0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int ii = lane * 4 + jj;
+            v[jj] = ii < npx ? s_cnt[ii] : 0;
+            sum += v[jj];
+        }
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        int run = incl - sum;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int ii = lane * 4 + jj;
+            if (ii < npx) s_start[ii] = run;
+            run += v[jj];
+        }
+        if (lane == 63) s_start[npx] = incl;       // == total (lanes beyond npx carry 0)
+    }
+    __syncthreads();
+    pass(1);
+    __syncthreads();
+    // B4: one half-wave per pixel row: sum its bucket in registers (16 row gathers in flight per
+    // lane - the pass is a pure L2 gather and lives on memory-level parallelism), one 128-byte
+    // atomic per row
+    const int c = threadIdx.x & 31;
+    constexpr int U = 16;
+    for (int p = threadIdx.x >> 5; p < npx; p += kGvThreads / 32) {
+        const int e0 = s_start[p], e1 = min(s_start[p + 1], cap);
+        float acc = 0.f;
+        for (int e = e0; e < e1; e += U) {
+            float g[U], w[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ee = min(e + u, e1 - 1);
+                const int2 en = *reinterpret_cast<const int2 *>(s_entries + 2 * ee);
+                w[u] = e + u < e1 ? __int_as_float(en.y) : 0.f;
+                g[u] = (float)grad_out[(int64_t)en.x * kD + c];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += w[u] * g[u];
+        }
+        if (e1 > e0) {
+            const int y = tm.y0 + p / tm.nx, x = tm.x0 + p % tm.nx;
+            atomicAdd(gv_level + ((int64_t)y * lv.W + x) * (int64_t)M * kD + c, acc);
+        }
+    }
+}
+
 struct FusedArgs {
     const void *value, *off, *logit, *grad_out;
     const int64_t *shapes, *lsi;
@@ -225,6 +513,9 @@ struct FusedArgs {
     void *out;
     float *grad_value;
     void *d_off, *d_logit;
+    const int *tile_meta = nullptr, *cand = nullptr;    // optional pull schedule
+    int64_t ntiles = 0, cap = 0;
+    float near_radius = -1.f;
     hipStream_t st;
 };
 
@@ -246,11 +537,37 @@ int launch_bwd(const FusedArgs &a) {
     const int64_t nblocks = (rows + (kBlock / kD) - 1) / (kBlock / kD);
     const int64_t grid = (nblocks + 7) / 8 * 8;
     if (grid >= ((int64_t)1 << 31)) return fail(VAH_E_SHAPE, "msda fused backward: grid too large");
-    hipLaunchKernelGGL((msda_fused_bwd<VT, PT, L, P>), dim3((unsigned)grid), dim3(kBlock), 0, a.st,
-                       (const VT *)a.value, a.shapes, a.lsi, (const PT *)a.off, (const PT *)a.logit, a.ref,
-                       a.ref_levels, (const VT *)a.grad_out, a.S, (int)a.M, a.Lq, rows, nblocks,
-                       a.grad_value, (PT *)a.d_off, (PT *)a.d_logit);
-    return check_launch("msda fused backward launch");
+    if (!a.tile_meta) {
+        hipLaunchKernelGGL((msda_fused_bwd<VT, PT, L, P>), dim3((unsigned)grid), dim3(kBlock), 0, a.st,
+                           (const VT *)a.value, a.shapes, a.lsi, (const PT *)a.off, (const PT *)a.logit, a.ref,
+                           a.ref_levels, (const VT *)a.grad_out, a.S, (int)a.M, a.Lq, rows, nblocks, -1.f,
+                           a.grad_value, (PT *)a.d_off, (PT *)a.d_logit);
+        return check_launch("msda fused backward launch");
+    }
+    {
+        const int64_t nb8 = (rows + (kBlock / 8) - 1) / (kBlock / 8);
+        const int64_t grid8 = (nb8 + 7) / 8 * 8;
+        hipLaunchKernelGGL((msda_fused_bwd_vec4<VT, PT, L, P>), dim3((unsigned)grid8), dim3(kBlock), 0, a.st,
+                           (const VT *)a.value, a.shapes, a.lsi, (const PT *)a.off, (const PT *)a.logit, a.ref,
+                           a.ref_levels, (const VT *)a.grad_out, a.S, (int)a.M, a.Lq, rows, nb8,
+                           a.near_radius, a.grad_value, (PT *)a.d_off, (PT *)a.d_logit);
+        if (int rc = check_launch("msda fused backward (split) launch")) return rc;
+    }
+    // pull pass for the near samples
+    const int64_t gblocks = a.N * a.M * a.ntiles;
+    if (gblocks >= ((int64_t)1 << 31)) return fail(VAH_E_SHAPE, "msda fused backward: tile grid too large");
+    const size_t smem = (size_t)a.cap * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)msda_fused_bwd_gv<VT, PT, L, P>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((msda_fused_bwd_gv<VT, PT, L, P>), dim3((unsigned)gblocks), dim3(kGvThreads), smem, a.st,
+                       a.shapes, a.lsi, (const PT *)a.off, (const PT *)a.logit, a.ref, a.ref_levels,
+                       (const VT *)a.grad_out, a.tile_meta, a.cand, (int)a.ntiles, a.S, (int)a.M, a.Lq,
+                       a.near_radius, (int)a.cap, a.grad_value);
+    return check_launch("msda fused backward (grad_value pull) launch");
 }
 
 template <bool BWD, typename VT, typename PT>
@@ -318,10 +635,14 @@ int vah_msda_fused_backward(const void *value, int value_dtype, const int64_t *s
                             const void *offsets, const void *logits, int param_dtype, const float *ref,
                             int64_t ref_levels, const void *grad_out, int64_t N, int64_t S, int64_t M,
                             int64_t D, int64_t L, int64_t Lq, int64_t P, float *grad_value,
-                            void *d_offsets, void *d_logits, void *stream) {
+                            void *d_offsets, void *d_logits, const int32_t *tile_meta,
+                            const int32_t *cand, int64_t ntiles, float near_radius, int64_t cap_entries,
+                            void *stream) {
     using namespace vah;
     clear_error();
     const char *fn = "vah_msda_fused_backward";
+    if (tile_meta && (!cand || ntiles < 1 || near_radius < 0.f || cap_entries < 64 || cap_entries * 8 > 150 * 1024))
+        return fail(VAH_E_SHAPE, "%s: bad pull schedule", fn);
     if (int rc = check_common(fn, N, S, M, D, L, Lq, P, ref_levels)) return rc;
     if (N * Lq * M == 0) return VAH_OK;
     if (!value || !shapes || !lsi || !offsets || !logits || !ref || !grad_out || !grad_value || !d_offsets || !d_logits)
@@ -330,6 +651,7 @@ int vah_msda_fused_backward(const void *value, int value_dtype, const int64_t *s
     a.value = value, a.off = offsets, a.logit = logits, a.shapes = shapes, a.lsi = lsi, a.ref = ref;
     a.ref_levels = (int)ref_levels, a.N = N, a.S = S, a.M = M, a.L = L, a.Lq = Lq, a.P = P;
     a.grad_out = grad_out, a.grad_value = grad_value, a.d_off = d_offsets, a.d_logit = d_logits;
+    a.tile_meta = tile_meta, a.cand = cand, a.ntiles = ntiles, a.cap = cap_entries, a.near_radius = near_radius;
     a.st = (hipStream_t)stream;
     LaunchScope scope("msda_fused_bwd", 4 * (2 * N * S * M * D + 6 * N * Lq * M * L * P + N * Lq * M * D), a.st);
     return dispatch<true>(a, value_dtype, param_dtype);

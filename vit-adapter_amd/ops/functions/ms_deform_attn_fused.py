@@ -26,6 +26,73 @@ def fused_supported(value, offsets, logits, reference_points, n_levels, n_points
             and value.numel() > 0 and offsets.numel() > 0)
 
 
+class PullSchedule:
+    """Tiles of the value maps + candidate query lists for the atomic-free grad_value pass
+    (include/vitadapter_hip.h, "PULL SCHEDULE").  Static per (reference grid, value shapes)."""
+
+    def __init__(self, tile_meta, cand, ntiles, radius, cap):
+        self.tile_meta, self.cand = tile_meta, cand
+        self.ntiles, self.radius, self.cap = int(ntiles), float(radius), int(cap)
+
+
+_PULL_CACHE = {}
+
+
+def build_pull_schedule(reference_points, value_shapes, radius=None, tile=None, n_points=4):
+    """reference_points (1, Lq, 1|L, 2) on the GPU, value_shapes [(H, W)] host ints.
+    Tile edge per level: 16 px where the level is sparsely sampled (few bucket entries per pixel),
+    else 8 px, so that a tile's bucket store (~ pixels x entries per pixel) fits one workgroup."""
+    radius = float(os.environ.get('VAH_MSDA_PULL_RADIUS', 5.0)) if radius is None else float(radius)
+    tile_env = int(os.environ.get('VAH_MSDA_PULL_TILE', 0)) if tile is None else int(tile)
+    dev = reference_points.device
+    ref = reference_points.detach().float()[0]                  # (Lq, RL, 2)
+    metas, cands, start = [], [], 0
+    margin = radius + 2.5
+    for l, (H, W) in enumerate(value_shapes):
+        per_px = ref.shape[0] * n_points * 4.0 / float(H * W)       # expected bucket entries per pixel
+        tile = tile_env if tile_env > 0 else (16 if per_px <= 12.0 else 8)
+        r = ref[:, l if ref.shape[1] > 1 else 0]
+        px, py = r[:, 0] * W - 0.5, r[:, 1] * H - 0.5
+        for y0 in range(0, H, tile):
+            ny = min(tile, H - y0)
+            in_y = (py >= y0 - margin) & (py <= y0 + ny - 1 + margin)
+            idx_y = in_y.nonzero().squeeze(1)
+            if idx_y.numel() == 0:
+                continue
+            pxs = px[idx_y]
+            for x0 in range(0, W, tile):
+                nx = min(tile, W - x0)
+                sel = idx_y[(pxs >= x0 - margin) & (pxs <= x0 + nx - 1 + margin)]
+                if sel.numel() == 0:
+                    continue
+                metas.append([l, y0, x0, ny, nx, start, int(sel.numel()), 0])
+                cands.append(sel.to(torch.int32))
+                start += int(sel.numel())
+    if not metas:
+        return None
+    meta = torch.tensor(metas, dtype=torch.int32, device=dev)
+    cand = torch.cat(cands).contiguous()
+    cap = int(os.environ.get('VAH_MSDA_PULL_CAP', 8192))
+    return PullSchedule(meta, cand, len(metas), radius, cap)
+
+
+def pull_schedule_for(reference_points, spatial_shapes):
+    """Cached per reference-point tensor (one host read of the (L, 2) shapes on the first call)."""
+    if os.environ.get('VAH_MSDA_PULL', '1') == '0':
+        return None
+    key = (reference_points.data_ptr(), tuple(reference_points.shape), reference_points._version,
+           spatial_shapes.data_ptr(), str(reference_points.device))
+    hit = _PULL_CACHE.get(key)
+    if hit is None:
+        shapes = [tuple(int(v) for v in hw) for hw in spatial_shapes.tolist()]
+        sched = build_pull_schedule(reference_points, shapes)
+        if len(_PULL_CACHE) > 64:
+            _PULL_CACHE.clear()
+        _PULL_CACHE[key] = (sched, reference_points, spatial_shapes)     # keep the keys' tensors alive
+        return sched
+    return hit[0]
+
+
 class MSDeformAttnFusedFunction(Function):
     """apply(value (N,S,M,32), spatial_shapes, level_start_index, offsets (N,Lq,M,L,P,2),
     logits (N,Lq,M,L*P), reference_points (1,Lq,1|L,2)) -> (N, Lq, M*32) in value's dtype."""
@@ -45,6 +112,7 @@ class MSDeformAttnFusedFunction(Function):
                 out.data_ptr(), torch.cuda.current_stream(value.device).cuda_stream)
         _vah.check(rc, 'vah_msda_fused_forward')
         ctx.save_for_backward(value, spatial_shapes, level_start_index, offsets, logits, ref)
+        ctx.pull = pull_schedule_for(reference_points, spatial_shapes)
         return out
 
     @staticmethod
@@ -57,12 +125,15 @@ class MSDeformAttnFusedFunction(Function):
         grad_value = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
         d_off = torch.empty_like(offsets)
         d_logit = torch.empty_like(logits)
+        pull = ctx.pull
         with torch.cuda.device(value.device):
             rc = _vah.lib.vah_msda_fused_backward(
                 value.data_ptr(), _DT[value.dtype], shapes.data_ptr(), lsi.data_ptr(),
                 offsets.data_ptr(), logits.data_ptr(), _DT[offsets.dtype], ref.data_ptr(),
                 ref.shape[1], grad_output.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
                 d_off.data_ptr(), d_logit.data_ptr(),
+                pull.tile_meta.data_ptr() if pull else None, pull.cand.data_ptr() if pull else None,
+                pull.ntiles if pull else 0, pull.radius if pull else -1.0, pull.cap if pull else 0,
                 torch.cuda.current_stream(value.device).cuda_stream)
         _vah.check(rc, 'vah_msda_fused_backward')
         return grad_value.to(value.dtype), None, None, d_off, d_logit, None
