@@ -148,7 +148,8 @@ int vah_msda_backward_win_f32(const float *value, const int64_t *shapes, const i
  * the tile rectangle (any superset is fine).  Samples whose offset is within near_radius pixels in
  * both axes are then accumulated per tile in LDS buckets and flushed with one atomic per pixel row;
  * the others are scattered with per-sample atomics as without a schedule.  cap_entries = capacity of
- * the per-workgroup bucket store (8 bytes each, <= 150 KiB); overflow falls back to atomics.  The
+ * the per-workgroup record store (10 bytes each, <= 150 KiB, even, < 65536); overflow falls back to
+ * atomics, as does the whole pass when N*Lq*M >= 2^24.  The
  * result is the same gradient (fp32 summation order aside) for any valid schedule.
  * ------------------------------------------------------------------------------------ */
 int vah_msda_fused_supported(int64_t D, int64_t L, int64_t P);

@@ -359,8 +359,11 @@ __global__ __launch_bounds__(kGvThreads) void msda_fused_bwd_gv(
     const VT *__restrict__ grad_out, const int *__restrict__ tile_meta, const int *__restrict__ cand,
     int ntiles, int64_t S, int M, int64_t Lq, float near_radius, int cap, float *__restrict__ grad_value) {
     constexpr int LP = L * P;
-    extern __shared__ __attribute__((aligned(16))) int s_entries[];        // cap x {row, weight bits}
+    // dynamic LDS: [records: cap x {row | px << 24, weight bits}] [order: cap x uint16]
+    extern __shared__ __attribute__((aligned(16))) int s_rec[];
+    unsigned short *s_order = reinterpret_cast<unsigned short *>(s_rec + 2 * (size_t)cap);
     __shared__ int s_cnt[kMaxTilePx], s_start[kMaxTilePx + 1], s_cur[kMaxTilePx];
+    __shared__ int s_total;
 
     const int64_t b = blockIdx.x;
     const int tile = (int)(b % ntiles);
@@ -373,47 +376,49 @@ __global__ __launch_bounds__(kGvThreads) void msda_fused_bwd_gv(
     if (!lv.valid || npx <= 0 || npx > kMaxTilePx || tm.cand_count <= 0) return;
 
     for (int i = threadIdx.x; i < npx; i += kGvThreads) s_cnt[i] = s_cur[i] = 0;
+    if (threadIdx.x == 0) s_total = 0;
     __syncthreads();
 
     const int nitems = tm.cand_count * P;
+    const int lane = threadIdx.x & 63;
     float *gv_level = grad_value + (n * S + lv.start) * (int64_t)M * kD + (int64_t)m * kD;
-    // One lane per (candidate query, point), IB items per lane in flight: the three dependent global
-    // reads of an item (candidate index -> offset / reference point -> logits) are issued for the
-    // whole batch before anything is consumed.  PASS 0 counts the bucket sizes, PASS 1 fills them.
+
+    // ---- 1: sample the candidates once; the (sample, corner) pairs that land in the tile are
+    // appended to the record list with a wave ballot (one LDS atomic per wave and corner, issued by
+    // one lane) - the hits are sparse (~20 % of the items), per-lane atomics here cost ~100 us.
     constexpr int IB = 4;
-    auto pass = [&](const int which) {
-        for (int base = threadIdx.x; base < nitems; base += kGvThreads * IB) {
-            int64_t qv[IB], rowv[IB];
-            float2 ov[IB], rpv[IB];
-            bool live[IB];
-            int pv[IB];
+    for (int base = threadIdx.x - lane; base < nitems; base += kGvThreads * IB) {      // wave-uniform trip count
+        int64_t qv[IB], rowv[IB];
+        float2 ov[IB], rpv[IB];
+        bool live[IB];
+        int pv[IB];
 #pragma unroll
-            for (int u = 0; u < IB; ++u) {
-                const int item = base + u * kGvThreads;
-                live[u] = item < nitems;
-                const int ci = live[u] ? item / P : 0;
-                pv[u] = live[u] ? item - ci * P : 0;
-                qv[u] = cand[tm.cand_start + ci];
-                live[u] = live[u] && qv[u] >= 0 && qv[u] < Lq;
-                if (!live[u]) qv[u] = 0;
-            }
+        for (int u = 0; u < IB; ++u) {
+            const int item = base + lane + u * kGvThreads;
+            live[u] = item < nitems;
+            const int ci = live[u] ? item / P : 0;
+            pv[u] = live[u] ? item - ci * P : 0;
+            qv[u] = cand[tm.cand_start + ci];
+            live[u] = live[u] && qv[u] >= 0 && qv[u] < Lq;
+            if (!live[u]) qv[u] = 0;
+        }
 #pragma unroll
-            for (int u = 0; u < IB; ++u) {
-                rowv[u] = (n * Lq + qv[u]) * M + m;
-                ov[u] = load2(off + (rowv[u] * LP + l * P + pv[u]) * 2);
-                rpv[u] = *reinterpret_cast<const float2 *>(ref + (qv[u] * ref_levels + (ref_levels > 1 ? l : 0)) * 2);
-            }
+        for (int u = 0; u < IB; ++u) {
+            rowv[u] = (n * Lq + qv[u]) * M + m;
+            ov[u] = load2(off + (rowv[u] * LP + l * P + pv[u]) * 2);
+            rpv[u] = *reinterpret_cast<const float2 *>(ref + (qv[u] * ref_levels + (ref_levels > 1 ? l : 0)) * 2);
+        }
 #pragma unroll
-            for (int u = 0; u < IB; ++u) {
-                if (!live[u]) continue;
-                if (!(fabsf(ov[u].x) <= near_radius && fabsf(ov[u].y) <= near_radius)) continue;   // far: kernel A
+        for (int u = 0; u < IB; ++u) {
+            int px[4] = {-1, -1, -1, -1};
+            float cw[4] = {0.f, 0.f, 0.f, 0.f};
+            bool any = false;
+            if (live[u] && fabsf(ov[u].x) <= near_radius && fabsf(ov[u].y) <= near_radius) {   // else far: kernel A
                 const Tap<float> t = make_tap<float>(rpv[u].x + ov[u].x / (float)lv.W,
                                                      rpv[u].y + ov[u].y / (float)lv.H, lv.H, lv.W);
-                int px[4];
-                bool any = false;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    px[k] = -1;
+                    cw[k] = t.cw[k];
                     if (!t.ok[k]) continue;
                     const int y = t.row[k] / lv.W, x = t.row[k] - y * lv.W;
                     const int ry = y - tm.y0, rx = x - tm.x0;
@@ -421,23 +426,24 @@ __global__ __launch_bounds__(kGvThreads) void msda_fused_bwd_gv(
                     px[k] = ry * tm.nx + rx;
                     any = true;
                 }
-                if (!any) continue;
-                if (which == 0) {
+            }
+            if (__ballot(any) == 0ull) continue;                    // wave-uniform
+            const float a = any ? softmax_weight<PT, LP>(logit + rowv[u] * LP, l * P + pv[u]) : 0.f;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (px[k] >= 0) atomicAdd(&s_cnt[px[k]], 1);
-                    continue;
-                }
-                const float a = softmax_weight<PT, LP>(logit + rowv[u] * LP, l * P + pv[u]);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (px[k] < 0) continue;
-                    const float w = t.cw[k] * a;
-                    const int slot = s_start[px[k]] + atomicAdd(&s_cur[px[k]], 1);
+            for (int k = 0; k < 4; ++k) {
+                const bool hit = px[k] >= 0;
+                const unsigned long long mask = __ballot(hit);
+                if (mask == 0ull) continue;                         // wave-uniform
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&s_total, __popcll(mask));
+                wbase = __shfl(wbase, 0, 64);
+                if (hit) {
+                    const int slot = wbase + __popcll(mask & ((1ull << lane) - 1ull));
+                    const float w = cw[k] * a;
                     if (slot < cap) {
-                        s_entries[2 * slot] = (int)rowv[u];
-                        s_entries[2 * slot + 1] = __float_as_int(w);
-                    } else {       // bucket store full: scatter directly (correct, just slow)
+                        s_rec[2 * slot] = (int)rowv[u] | (px[k] << 24);
+                        s_rec[2 * slot + 1] = __float_as_int(w);
+                    } else {       // record store full: scatter directly (correct, just slow)
                         const int y = tm.y0 + px[k] / tm.nx, x = tm.x0 + px[k] % tm.nx;
                         float *dst = gv_level + ((int64_t)y * lv.W + x) * (int64_t)M * kD;
                         for (int c = 0; c < kD; ++c) atomicAdd(dst + c, w * (float)grad_out[rowv[u] * kD + c]);
@@ -445,13 +451,14 @@ __global__ __launch_bounds__(kGvThreads) void msda_fused_bwd_gv(
                 }
             }
         }
-    };
-
-    pass(0);
+    }
     __syncthreads();
-    // exclusive scan of the bucket sizes (<= 256 buckets): one wave, 4 buckets per lane
+    const int nrec = min(s_total, cap);
+    // ---- 2: bucket sizes, dense (every lane holds a record)
+    for (int r = threadIdx.x; r < nrec; r += kGvThreads) atomicAdd(&s_cnt[(unsigned)s_rec[2 * r] >> 24], 1);
+    __syncthreads();
+    // ---- 3: exclusive scan of the bucket sizes (<= 256 buckets): one wave, 4 buckets per lane
     if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
         int v[4], sum = 0;
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -472,27 +479,31 @@ __global__ __launch_bounds__(kGvThreads) void msda_fused_bwd_gv(
             if (ii < npx) s_start[ii] = run;
             run += v[jj];
         }
-        if (lane == 63) s_start[npx] = incl;       // == total (lanes beyond npx carry 0)
+        if (lane == 63) s_start[npx] = incl;
     }
     __syncthreads();
-    pass(1);
+    // ---- 4: order[] = record indices grouped by pixel
+    for (int r = threadIdx.x; r < nrec; r += kGvThreads) {
+        const int px = (unsigned)s_rec[2 * r] >> 24;
+        s_order[s_start[px] + atomicAdd(&s_cur[px], 1)] = (unsigned short)r;
+    }
     __syncthreads();
-    // B4: one half-wave per pixel row: sum its bucket in registers (16 row gathers in flight per
+    // ---- 5: one half-wave per pixel row: sum its bucket in registers (16 row gathers in flight per
     // lane - the pass is a pure L2 gather and lives on memory-level parallelism), one 128-byte
     // atomic per row
     const int c = threadIdx.x & 31;
     constexpr int U = 16;
     for (int p = threadIdx.x >> 5; p < npx; p += kGvThreads / 32) {
-        const int e0 = s_start[p], e1 = min(s_start[p + 1], cap);
+        const int e0 = s_start[p], e1 = s_start[p + 1];
         float acc = 0.f;
         for (int e = e0; e < e1; e += U) {
             float g[U], w[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const int ee = min(e + u, e1 - 1);
-                const int2 en = *reinterpret_cast<const int2 *>(s_entries + 2 * ee);
+                const int r = s_order[min(e + u, e1 - 1)];
+                const int2 en = *reinterpret_cast<const int2 *>(s_rec + 2 * r);
                 w[u] = e + u < e1 ? __int_as_float(en.y) : 0.f;
-                g[u] = (float)grad_out[(int64_t)en.x * kD + c];
+                g[u] = (float)grad_out[(int64_t)(en.x & 0xFFFFFF) * kD + c];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) acc += w[u] * g[u];
@@ -556,7 +567,7 @@ int launch_bwd(const FusedArgs &a) {
     // pull pass for the near samples
     const int64_t gblocks = a.N * a.M * a.ntiles;
     if (gblocks >= ((int64_t)1 << 31)) return fail(VAH_E_SHAPE, "msda fused backward: tile grid too large");
-    const size_t smem = (size_t)a.cap * 8;
+    const size_t smem = (size_t)a.cap * 10;      // records (8 B) + order (2 B)
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)msda_fused_bwd_gv<VT, PT, L, P>,
@@ -641,8 +652,10 @@ int vah_msda_fused_backward(const void *value, int value_dtype, const int64_t *s
     using namespace vah;
     clear_error();
     const char *fn = "vah_msda_fused_backward";
-    if (tile_meta && (!cand || ntiles < 1 || near_radius < 0.f || cap_entries < 64 || cap_entries * 8 > 150 * 1024))
+    if (tile_meta && (!cand || ntiles < 1 || near_radius < 0.f || cap_entries < 64 || cap_entries * 10 > 150 * 1024 ||
+                      cap_entries > 65535 || (cap_entries & 1)))
         return fail(VAH_E_SHAPE, "%s: bad pull schedule", fn);
+    if (tile_meta && N * Lq * M >= (1 << 24)) tile_meta = nullptr;     // packed row index has 24 bits: plain path
     if (int rc = check_common(fn, N, S, M, D, L, Lq, P, ref_levels)) return rc;
     if (N * Lq * M == 0) return VAH_OK;
     if (!value || !shapes || !lsi || !offsets || !logits || !ref || !grad_out || !grad_value || !d_offsets || !d_logits)

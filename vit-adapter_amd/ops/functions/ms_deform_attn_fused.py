@@ -72,7 +72,7 @@ def build_pull_schedule(reference_points, value_shapes, radius=None, tile=None, 
         return None
     meta = torch.tensor(metas, dtype=torch.int32, device=dev)
     cand = torch.cat(cands).contiguous()
-    cap = int(os.environ.get('VAH_MSDA_PULL_CAP', 8192))
+    cap = int(os.environ.get('VAH_MSDA_PULL_CAP', 7168))      # 70 KB of LDS: two workgroups per CU
     return PullSchedule(meta, cand, len(metas), radius, cap)
 
 
