@@ -229,9 +229,41 @@ int vah_attn_win_bwd_bf16(const void *q, const void *k, const void *v, int64_t l
 int64_t vah_reduce_ws_floats(int64_t K);
 int vah_layernorm_fwd_f32_bf16(const float *x, const float *w, const float *b, int64_t rows, int64_t C,
                                float eps, void *y_bf16, float *mean, float *rstd, void *stream);
+/* gres (fp32 (rows, C) or NULL): gradient that reaches x along the residual branch; when given,
+ * dx = gres + LayerNorm'(g) - the sum autograd would otherwise form with a separate add. */
 int vah_layernorm_bwd_f32_bf16(const float *x, const void *g_bf16, const float *w, const float *mean,
-                               const float *rstd, int64_t rows, int64_t C,
+                               const float *rstd, const float *gres, int64_t rows, int64_t C,
                                float *dx, float *dw, float *db, float *ws /* K = 2C */, void *stream);
+/* out[c] = sum_r g[r][c] of a bf16 (rows, C) matrix, C % 8 == 0: the bias gradient of nn.Linear
+ * (what autograd computes as grad_output.sum(0)); ws K = C. */
+int vah_colsum_bf16(const void *g_bf16, int64_t rows, int64_t C, float *out, float *ws, void *stream);
+
+/* ---- bf16 GEMMs of the Linear layers (csrc/gemm.hip) ----------------------------------------
+ * D (M x N, row-major, leading dimension ldd; bf16, or fp32 when d_is_f32) = op(A) op(B), bf16
+ * operands, fp32 accumulation.  trans_a: A is stored (K x M) row-major and used transposed;
+ * trans_b likewise (B stored (N x K)).  Replaces F.linear and its backward products
+ * (torch addmm / mm on hipBLASLt): forward  y = x W^T + b   (trans_b = 1, EPI_BIAS),
+ * input gradient  dx = g W   and weight gradient  dW = g^T x  (trans_a = 1, fp32 output).
+ * Epilogues: BIAS adds bias[N] (bf16 or fp32); BIAS_GELU_AUX also stores the pre-activation in
+ * aux (bf16, ld_aux) and applies GELU (tanh-free erf form of hipBLASLt); DGELU multiplies by
+ * GELU'(aux); BGRAD_A additionally writes sum over K of A (the bias gradient when A = g^T) to bias.
+ * The library times the hipBLASLt candidates of every new problem once on the caller's stream
+ * (vah_gemm_set_tuning: mode 0 = first heuristic answer, 1 = time `candidates` heuristic answers
+ * [default, 32], 2 = time every algorithm of the library) and caches the winner; the cache can be
+ * dumped / loaded as text ("ta tb d32 epi bias32 M N K lda ldb ldd algo_index us" per line).
+ * workspace: caller-provided scratch (32 MiB is ample), private to the stream. */
+#define VAH_GEMM_EPI_NONE 0
+#define VAH_GEMM_EPI_BIAS 1
+#define VAH_GEMM_EPI_BIAS_GELU_AUX 2
+#define VAH_GEMM_EPI_DGELU 3
+#define VAH_GEMM_EPI_BGRAD_A 4
+int vah_gemm_set_tuning(int mode, int candidates);
+int vah_gemm_bf16(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
+                  const void *B, int64_t ldb, void *D, int64_t ldd, int d_is_f32, int epilogue,
+                  const void *bias, int bias_is_f32, void *aux, int64_t ld_aux, void *workspace,
+                  int64_t workspace_bytes, void *stream);
+int64_t vah_gemm_table_dump(char *buf, int64_t cap);   /* returns the size needed (incl. NUL) */
+int vah_gemm_table_load(const char *text);             /* returns the number of entries, < 0 on error */
 /* y = x + s[b] * gamma[c] * z   (x, y fp32 (batch, rows_per_batch, C); z bf16; gamma (C) or NULL;
  * s (batch) or NULL): the residual update  x + drop_path(gamma * branch(x))  of base/vit.py:301-306
  * and adapter_modules.py:112-117,145.  Backward: dz (bf16) and dgamma (NULL when gamma is NULL;

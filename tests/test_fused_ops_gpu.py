@@ -123,3 +123,133 @@ def test_block_under_autocast_matches_unfused():
         fused.ENABLED[k] = True
     for a, b, nm in zip(outs[0], outs[1], ('y', 'dx', 'dgamma1', 'dnorm1.w')):
         _close(a, b, 3e-2, nm)
+
+
+@pytest.mark.parametrize('shape', [(2, 100, 192), (1, 513, 768)])
+def test_layer_norm_keep_sums_both_gradients(shape):
+    """x + branch(LN(x)): the residual gradient and the LayerNorm gradient are summed inside the
+    backward kernel; result = what autograd's separate add gives."""
+    from vitadapter import fused
+    torch.manual_seed(3)
+    ln = torch.nn.LayerNorm(shape[-1], eps=1e-6).cuda()
+    x = (torch.randn(shape, device='cuda') * 2 + 0.5).requires_grad_(True)
+    g_res = torch.randn(shape, device='cuda')
+    g_ln = torch.randn(shape, device='cuda').to(torch.bfloat16)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        xk, h = fused.layer_norm_keep(ln, x * 1.0)
+    assert h.dtype == torch.bfloat16 and xk.dtype == torch.float32
+    torch.autograd.backward([xk, h], [g_res, g_ln])
+    got = x.grad.clone()
+    gw = ln.weight.grad.clone()
+    x.grad = None
+    ln.zero_grad()
+    xr = x * 1.0
+    torch.autograd.backward([xr, ln(xr)], [g_res, g_ln.float()])
+    _close(got, x.grad, 1e-4, 'dx')
+    _close(gw, ln.weight.grad, 1e-3, 'dw')
+    # only one of the two outputs used
+    x.grad = None
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        xk, h = fused.layer_norm_keep(ln, x * 1.0)
+    xk.backward(g_res)
+    _close(x.grad, g_res, 1e-7, 'dx (residual only)')
+    x.grad = None
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        xk, h = fused.layer_norm_keep(ln, x * 1.0)
+    h.backward(g_ln)
+    got = x.grad.clone()
+    x.grad = None
+    ln(x).backward(g_ln.float())
+    _close(got, x.grad, 1e-4, 'dx (LN only)')
+
+
+@pytest.mark.parametrize('rows,C', [(8192, 768), (43008, 96), (100, 2304), (1, 8), (33, 3072), (0, 64)])
+def test_colsum_bf16(rows, C):
+    import _vah
+    torch.manual_seed(4)
+    g = torch.randn(rows, C, device='cuda').to(torch.bfloat16)
+    out = torch.full((C,), float('nan'), device='cuda')
+    ws = torch.empty(_vah.lib.vah_reduce_ws_floats(C), device='cuda')
+    _vah.check(_vah.lib.vah_colsum_bf16(g.data_ptr(), rows, C, out.data_ptr(), ws.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream), 'colsum')
+    ref = g.double().sum(0)
+    assert (out.double() - ref).abs().max().item() <= 1e-5 * max(1.0, rows ** 0.5) * 4
+
+
+@pytest.mark.parametrize('shape,out_f,bias', [((2, 300, 768), 2304, True), ((2, 300, 768), 768, False),
+                                             ((1, 21, 192), 96, True), ((64, 3072), 768, True)])
+def test_linear_bf16_matches_autocast(shape, out_f, bias):
+    """fused.linear = F.linear under bf16 autocast: same forward bits, input gradient to bf16
+    rounding, weight / bias gradients at least as close to the fp32 result as autocast's."""
+    from vitadapter import fused
+    torch.manual_seed(5)
+    lin = torch.nn.Linear(shape[-1], out_f, bias=bias).cuda()
+    x = torch.randn(shape, device='cuda').to(torch.bfloat16).requires_grad_(True)
+    g = torch.randn(shape[:-1] + (out_f,), device='cuda').to(torch.bfloat16)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        y = fused.linear(lin, x)
+    assert y.dtype == torch.bfloat16
+    y.backward(g)
+    got = [y.detach().clone(), x.grad.clone(), lin.weight.grad.clone()] + ([lin.bias.grad.clone()] if bias else [])
+    assert lin.weight.grad.dtype == torch.float32
+    x.grad = None
+    lin.zero_grad()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        yr = lin(x)
+    yr.backward(g)
+    _close(got[0], yr, 1e-2, 'y')
+    _close(got[1], x.grad, 1e-2, 'dx')
+    # fp32 truth of the parameter gradients from the same bf16 operands
+    g2, x2 = g.reshape(-1, out_f).double(), x.detach().reshape(-1, shape[-1]).double()
+    gw = g2.t() @ x2
+    e_ours = (got[2].double() - gw).abs().max().item()
+    e_amp = (lin.weight.grad.double() - gw).abs().max().item()
+    assert e_ours <= max(e_amp, 1e-3 * gw.abs().max().item()), (e_ours, e_amp)
+    if bias:
+        gb = g2.sum(0)
+        assert (got[3].double() - gb).abs().max().item() <= 1e-4 * max(1.0, gb.abs().max().item())
+    # parameters updated in place (optimizer step): the bf16 copy follows
+    with torch.no_grad():
+        lin.weight.mul_(0.5)
+    fused.refresh_linear_copies(lin)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        fused.refresh_linear_copies(lin)
+        y2 = fused.linear(lin, x)
+        y2r = lin(x)
+    _close(y2, y2r, 1e-2, 'y after update')
+    assert fused.linear(lin, x.float()).dtype == torch.float32       # no autocast -> plain nn.Linear
+
+
+@pytest.mark.parametrize('ta,tb', [(False, False), (False, True), (True, False), (True, True)])
+@pytest.mark.parametrize('M,N,K,f32', [(300, 768, 192, False), (768, 2304, 600, True), (8, 8, 8, False),
+                                       (129, 96, 1000, True)])
+def test_gemm_bf16_dispatcher(ta, tb, M, N, K, f32):
+    """csrc/gemm.hip against torch.matmul in fp64 on the same bf16 operands."""
+    from vitadapter import fused
+    torch.manual_seed(6)
+    a = torch.randn((K, M) if ta else (M, K), device='cuda').to(torch.bfloat16)
+    b = torch.randn((N, K) if tb else (K, N), device='cuda').to(torch.bfloat16)
+    bias = torch.randn(N, device='cuda')
+    ref = (a.double().t() if ta else a.double()) @ (b.double().t() if tb else b.double())
+    d = fused.gemm_bf16(a, b, ta, tb, torch.float32 if f32 else torch.bfloat16)
+    tol = (1e-5 if f32 else 8e-3) * max(1.0, ref.abs().max().item())
+    assert (d.double() - ref).abs().max().item() <= tol
+    d = fused.gemm_bf16(a, b, ta, tb, torch.float32 if f32 else torch.bfloat16, bias=bias)
+    assert (d.double() - (ref + bias.double())).abs().max().item() <= tol
+    d2 = fused.gemm_bf16(a, b, ta, tb, torch.float32 if f32 else torch.bfloat16, bias=bias)
+    assert torch.equal(d, d2)                      # cached algorithm: deterministic replay
+
+
+def test_gemm_table_roundtrip():
+    import _vah
+    from vitadapter import fused
+    a = torch.randn(64, 128, device='cuda').to(torch.bfloat16)
+    b = torch.randn(128, 256, device='cuda').to(torch.bfloat16)
+    d = fused.gemm_bf16(a, b)
+    text = _vah.gemm_table_dump()
+    line = [ln for ln in text.splitlines() if ln.startswith('0 0 0 0 0 64 256 128 ')]
+    assert len(line) == 1, text
+    assert _vah.gemm_table_load(text) == len(text.splitlines())
+    assert torch.equal(fused.gemm_bf16(a, b), d)   # entries are re-resolved from their index
+    with pytest.raises(RuntimeError):
+        _vah.gemm_table_load('not a table line')

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
-ABI_VERSION = 10
+ABI_VERSION = 12
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -71,7 +71,15 @@ lib.vah_msda_fused_backward.argtypes = ([_p, _ci, _p, _p, _p, _p, _ci, _p, _i64,
 lib.vah_msda_fused_backward.restype = ctypes.c_int
 _f = ctypes.c_float
 lib.vah_layernorm_fwd_f32_bf16.argtypes = [_p, _p, _p, _i64, _i64, _f, _p, _p, _p, _p]
-lib.vah_layernorm_bwd_f32_bf16.argtypes = [_p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p]
+lib.vah_layernorm_bwd_f32_bf16.argtypes = [_p, _p, _p, _p, _p, _p, _i64, _i64, _p, _p, _p, _p, _p]
+lib.vah_colsum_bf16.argtypes = [_p, _i64, _i64, _p, _p, _p]
+_int = ctypes.c_int
+lib.vah_gemm_set_tuning.argtypes = [_int, _int]
+lib.vah_gemm_bf16.argtypes = [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _int, _int, _p, _int,
+                              _p, _i64, _p, _i64, _p]
+lib.vah_gemm_table_dump.argtypes = [ctypes.c_char_p, _i64]
+lib.vah_gemm_table_dump.restype = _i64
+lib.vah_gemm_table_load.argtypes = [ctypes.c_char_p]
 lib.vah_reduce_ws_floats.argtypes = [_i64]
 lib.vah_reduce_ws_floats.restype = _i64
 lib.vah_scale_residual_fwd.argtypes = [_p, _p, _p, _p, _i64, _i64, _i64, _p, _p]
@@ -79,7 +87,8 @@ lib.vah_scale_residual_bwd.argtypes = [_p, _p, _p, _p, _i64, _i64, _i64, _p, _p,
 lib.vah_dwconv3x3_tokens_bf16.argtypes = [_p, _p, _p, _i64, _i64, _i64, _i64, ctypes.c_int, _p, _p]
 lib.vah_dwconv3x3_tokens_wgrad_bf16.argtypes = [_p, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _p]
 for _n in ('vah_layernorm_fwd_f32_bf16', 'vah_layernorm_bwd_f32_bf16', 'vah_scale_residual_fwd',
-           'vah_scale_residual_bwd', 'vah_dwconv3x3_tokens_bf16', 'vah_dwconv3x3_tokens_wgrad_bf16'):
+           'vah_scale_residual_bwd', 'vah_dwconv3x3_tokens_bf16', 'vah_dwconv3x3_tokens_wgrad_bf16',
+           'vah_colsum_bf16', 'vah_gemm_set_tuning', 'vah_gemm_bf16', 'vah_gemm_table_load'):
     getattr(lib, _n).restype = ctypes.c_int
 
 if lib.vah_abi_version() != ABI_VERSION:
@@ -96,7 +105,8 @@ EXPORTS = (
     'vah_attn_padded_len', 'vah_attn_fwd_bf16', 'vah_attn_bwd_workspace_bytes', 'vah_attn_bwd_bf16',
     'vah_attn_win_fwd_bf16', 'vah_attn_win_bwd_bf16',
     'vah_reduce_ws_floats', 'vah_layernorm_fwd_f32_bf16', 'vah_layernorm_bwd_f32_bf16', 'vah_scale_residual_fwd',
-    'vah_scale_residual_bwd', 'vah_dwconv3x3_tokens_bf16', 'vah_dwconv3x3_tokens_wgrad_bf16',
+    'vah_scale_residual_bwd', 'vah_dwconv3x3_tokens_bf16', 'vah_dwconv3x3_tokens_wgrad_bf16', 'vah_colsum_bf16',
+    'vah_gemm_set_tuning', 'vah_gemm_bf16', 'vah_gemm_table_dump', 'vah_gemm_table_load',
 )
 
 
@@ -121,3 +131,21 @@ def prof_report():
         name, calls, ms, nbytes = line.split()
         out[name] = dict(calls=int(calls), total_ms=float(ms), bytes=int(nbytes))
     return out
+
+
+GEMM_EPI_NONE, GEMM_EPI_BIAS, GEMM_EPI_BIAS_GELU_AUX, GEMM_EPI_DGELU, GEMM_EPI_BGRAD_A = range(5)
+
+
+def gemm_table_dump():
+    """The GEMM algorithm cache as text (one problem per line, see include/vitadapter_hip.h)."""
+    n = lib.vah_gemm_table_dump(None, 0)
+    buf = ctypes.create_string_buffer(int(n))
+    lib.vah_gemm_table_dump(buf, n)
+    return buf.value.decode()
+
+
+def gemm_table_load(text):
+    n = lib.vah_gemm_table_load(text.encode())
+    if n < 0:
+        check(n, 'gemm_table_load')
+    return n

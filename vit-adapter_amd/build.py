@@ -45,7 +45,8 @@ def build(force=False, verbose=False):
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)
     if force or _newer(LIB, objs):
-        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + [
+            '-L/opt/rocm/lib', '-lhipblaslt']       # resolved at run time by the copy torch has loaded
         if verbose:
             print(' '.join(cmd), flush=True)
         subprocess.check_call(cmd)

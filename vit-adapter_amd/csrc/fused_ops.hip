@@ -14,12 +14,15 @@
 //                          (ref: segmentation/mmseg_custom/models/backbones/adapter_modules.py:72-87):
 //                          no slice / transpose / contiguous / cat copies, no MIOpen naive bf16
 //                          depthwise kernels (3.3 ms per step measured)
+#include <algorithm>
+
 #include "common.h"
 
 namespace vah {
 namespace {
 
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 
 __device__ __forceinline__ float wave_sum(float x) {
     x = dpp_sum16(x);
@@ -127,7 +130,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ x
                                                      const __bf16 *__restrict__ g,
                                                      const float *__restrict__ w,
                                                      const float *__restrict__ mean,
-                                                     const float *__restrict__ rstd, int64_t rows, int C,
+                                                     const float *__restrict__ rstd,
+                                                     const float *__restrict__ gres, int64_t rows, int C,
                                                      float *__restrict__ dx, float *__restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float s_red[];      // [4][2C]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -170,13 +174,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ x
         }
         const float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
         float *dr = dx + row * C;
+        const float *rr = gres ? gres + row * C : nullptr;      // gradient of the residual branch of x
 #pragma unroll
         for (int j = 0; j < kMaxVec; ++j) {
             const int i = lane + 64 * j;
-            if (i < nvec)
+            if (i < nvec) {
+                float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (rr) r = *reinterpret_cast<const float4 *>(rr + 4 * i);
                 *reinterpret_cast<float4 *>(dr + 4 * i) =
-                    make_float4(rs * (gw[j].x - m1 - xh[j].x * m2), rs * (gw[j].y - m1 - xh[j].y * m2),
-                                rs * (gw[j].z - m1 - xh[j].z * m2), rs * (gw[j].w - m1 - xh[j].w * m2));
+                    make_float4(r.x + rs * (gw[j].x - m1 - xh[j].x * m2), r.y + rs * (gw[j].y - m1 - xh[j].y * m2),
+                                r.z + rs * (gw[j].z - m1 - xh[j].z * m2), r.w + rs * (gw[j].w - m1 - xh[j].w * m2));
+            }
         }
     }
 #pragma unroll
@@ -191,6 +199,48 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ x
     float *pr = part + (int64_t)blockIdx.x * 2 * C;
     for (int k = threadIdx.x; k < 2 * C; k += 256)
         pr[k] = s_red[k] + s_red[2 * C + k] + s_red[4 * C + k] + s_red[6 * C + k];
+}
+
+// ---------------------------------------------------------------------------------------
+// Column sums of a bf16 [rows, C] matrix (bias gradient of a Linear).  Workgroup = 32 column lanes
+// (8 bf16 = 16 bytes each: 256 columns) x 8 row lanes over a strip of rows; one partial row each.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16 *__restrict__ g, int64_t rows,
+                                                          int C, int rows_per_block,
+                                                          float *__restrict__ part) {
+    __shared__ float s_acc[8][256 + 8];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 256 + cl * 8;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = min(rows, r0 + rows_per_block);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c0 < C) {
+        int64_t r = r0 + rl;
+        for (; r + 24 < r1; r += 32) {           // 4 independent 16-byte loads in flight
+            bf16x8 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const bf16x8 *>(g + (r + 8 * u) * C + c0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)v[u][e];
+        }
+        for (; r < r1; r += 8) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8 *>(g + r * C + c0);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s_acc[rl][cl * 8 + e] = acc[e];
+    __syncthreads();
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += s_acc[u][threadIdx.x];
+        part[(int64_t)blockIdx.y * C + c] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -408,8 +458,8 @@ int64_t vah_reduce_ws_floats(int64_t K) { return (int64_t)vah::kMaxParts * K; }
 
 // ws: vah_reduce_ws_floats(2*C) floats of scratch.  dw, db are overwritten.
 int vah_layernorm_bwd_f32_bf16(const float *x, const void *g, const float *w, const float *mean,
-                               const float *rstd, int64_t rows, int64_t C, float *dx, float *dw,
-                               float *db, float *ws, void *stream) {
+                               const float *rstd, const float *gres, int64_t rows, int64_t C, float *dx,
+                               float *dw, float *db, float *ws, void *stream) {
     using namespace vah;
     clear_error();
     const char *fn = "vah_layernorm_bwd_f32_bf16";
@@ -422,14 +472,14 @@ int vah_layernorm_bwd_f32_bf16(const float *x, const void *g, const float *w, co
         return VAH_OK;
     }
     if (!x || !g || !w || !mean || !rstd || !dx) return fail(VAH_E_NULL, "%s: null pointer", fn);
-    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)dx) % 16 || (uintptr_t)g % 8) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)dx | (uintptr_t)gres) % 16 || (uintptr_t)g % 8) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
     int64_t nblocks = (rows + 3) / 4;
     if (nblocks > kMaxParts) nblocks = kMaxParts;
     const size_t smem = (size_t)8 * C * sizeof(float);
     LaunchScope scope("layernorm_bwd", rows * C * 10, st);
 #define VAH_LN_BWD(NV)                                                                          \
     hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3((unsigned)nblocks), dim3(256), smem, st, x,      \
-                       (const __bf16 *)g, w, mean, rstd, rows, (int)C, dx, ws)
+                       (const __bf16 *)g, w, mean, rstd, gres, rows, (int)C, dx, ws)
     if (C <= 256) VAH_LN_BWD(1);
     else if (C <= 512) VAH_LN_BWD(2);
     else if (C <= 1024) VAH_LN_BWD(4);
@@ -437,6 +487,33 @@ int vah_layernorm_bwd_f32_bf16(const float *x, const void *g, const float *w, co
 #undef VAH_LN_BWD
     hipLaunchKernelGGL(finalize_partials, dim3((unsigned)((2 * C + 31) / 32)), dim3(256), 0, st, ws,
                        (int)nblocks, (int)(2 * C), dw, (int)C, db);
+    return check_launch(fn);
+}
+
+// out[c] = sum_r g[r][c] for a bf16 [rows, C] matrix, C % 8 == 0; ws: vah_reduce_ws_floats(C).
+int vah_colsum_bf16(const void *g, int64_t rows, int64_t C, float *out, float *ws, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_colsum_bf16";
+    if (rows < 0 || C < 8 || C % 8 || C > (1 << 20)) return fail(VAH_E_SHAPE, "%s: C=%lld unsupported", fn, (long long)C);
+    if (!out || !ws) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) {
+        (void)hipMemsetAsync(out, 0, C * 4, st);
+        return VAH_OK;
+    }
+    if (!g) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if ((uintptr_t)g % 16) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    const int ctiles = (int)((C + 255) / 256);
+    // enough strips to fill the chip, at least 32 rows each, at most kMaxParts partial rows
+    int64_t parts = std::min<int64_t>(kMaxParts, std::max<int64_t>(1, 2048 / ctiles));
+    int64_t rpb = std::max<int64_t>(32, (rows + parts - 1) / parts);
+    parts = (rows + rpb - 1) / rpb;
+    LaunchScope scope("colsum_bf16", rows * C * 2, st);
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)ctiles, (unsigned)parts), dim3(256), 0, st,
+                       (const __bf16 *)g, rows, (int)C, (int)rpb, ws);
+    hipLaunchKernelGGL(finalize_partials, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, st, ws, (int)parts,
+                       (int)C, out, (int)C, (float *)nullptr);
     return check_launch(fn);
 }
 

@@ -1,0 +1,356 @@
+// bf16 GEMMs of the Linear layers (reference: every nn.Linear of base/vit.py, adapter_modules.py and
+// ops/modules/ms_deform_attn.py, i.e. F.linear and its two backward products).
+//
+// The tiles come from hipBLASLt (plain library GEMMs are the one place a library is the right
+// tool); what lives here is the part the framework path does badly on this workload:
+//   * algorithm choice.  hipBLASLt's first heuristic answer is up to 5x off for the tall-skinny
+//     weight-gradient products (K = 8192..43008 rows, 768x768..3072 outputs).  Every distinct
+//     problem is timed once, on first use, over the heuristic candidates (or over every algorithm
+//     of the library in exhaustive mode) and the winner is cached; the table can be dumped and
+//     loaded as text so a tuned table can be shipped.
+//   * the weight gradient is written in fp32 straight from the accumulators (no bf16 rounding of
+//     the gradient and no cast kernel per parameter).
+// Row-major in, row-major out; hipBLASLt is column-major, so D^T = op(B)^T op(A)^T is what is run.
+#include <hip/hip_runtime.h>
+#include <hipblaslt/hipblaslt-ext.hpp>
+#include <hipblaslt/hipblaslt.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/vitadapter_hip.h"
+#include "common.h"
+
+namespace vah {
+namespace {
+
+struct Key {
+    int ta, tb, d32, epi, bias32;
+    int64_t M, N, K, lda, ldb, ldd;
+    bool operator<(const Key &o) const {
+        return std::tie(ta, tb, d32, epi, bias32, M, N, K, lda, ldb, ldd) <
+               std::tie(o.ta, o.tb, o.d32, o.epi, o.bias32, o.M, o.N, o.K, o.lda, o.ldb, o.ldd);
+    }
+};
+
+struct Choice {
+    hipblasLtMatmulAlgo_t algo;
+    size_t workspace = 0;
+    int index = -1;          // hipblaslt_ext algorithm index (stable within one library build)
+    float us = 0.f;          // measured time of the winner (0: not measured)
+    bool resolved = false;   // algo valid (an entry loaded from text is resolved on first use)
+};
+
+struct State {
+    std::mutex mu;
+    hipblasLtHandle_t handle = nullptr;
+    std::map<Key, Choice> table;
+    int mode = 1;            // 0: first heuristic answer, 1: time the heuristic candidates, 2: time all
+    int candidates = 32;
+};
+
+State &state() {
+    static State s;
+    return s;
+}
+
+const char *status_name(hipblasStatus_t s) {
+    switch (s) {
+    case HIPBLAS_STATUS_SUCCESS: return "success";
+    case HIPBLAS_STATUS_NOT_INITIALIZED: return "not initialized";
+    case HIPBLAS_STATUS_ALLOC_FAILED: return "alloc failed";
+    case HIPBLAS_STATUS_INVALID_VALUE: return "invalid value";
+    case HIPBLAS_STATUS_NOT_SUPPORTED: return "not supported";
+    case HIPBLAS_STATUS_EXECUTION_FAILED: return "execution failed";
+    default: return "error";
+    }
+}
+
+// RAII over the descriptor set of one problem.
+struct Problem {
+    hipblasLtMatmulDesc_t desc = nullptr;
+    hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, ld = nullptr;
+    ~Problem() {
+        if (la) hipblasLtMatrixLayoutDestroy(la);
+        if (lb) hipblasLtMatrixLayoutDestroy(lb);
+        if (ld) hipblasLtMatrixLayoutDestroy(ld);
+        if (desc) hipblasLtMatmulDescDestroy(desc);
+    }
+};
+
+struct Call {
+    Key k;
+    const void *A, *B, *bias;
+    void *D, *aux;
+    int64_t ld_aux;
+    void *ws;
+    size_t ws_bytes;
+    hipStream_t st;
+};
+
+hipblasStatus_t make_problem(const Call &c, Problem &p) {
+    const Key &k = c.k;
+    hipblasStatus_t s = hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F);
+    if (s != HIPBLAS_STATUS_SUCCESS) return s;
+    // column-major view: first operand = our B, second = our A
+    const hipblasOperation_t op1 = k.tb ? HIPBLAS_OP_T : HIPBLAS_OP_N, op2 = k.ta ? HIPBLAS_OP_T : HIPBLAS_OP_N;
+    hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op1, sizeof(op1));
+    hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &op2, sizeof(op2));
+    // our B row-major: (K x N) [tb = 0] or (N x K) [tb = 1]; as column-major (N x K) resp. (K x N)
+    s = hipblasLtMatrixLayoutCreate(&p.la, HIP_R_16BF, k.tb ? k.K : k.N, k.tb ? k.N : k.K, k.ldb);
+    if (s != HIPBLAS_STATUS_SUCCESS) return s;
+    // our A row-major: (M x K) [ta = 0] or (K x M) [ta = 1]; as column-major (K x M) resp. (M x K)
+    s = hipblasLtMatrixLayoutCreate(&p.lb, HIP_R_16BF, k.ta ? k.M : k.K, k.ta ? k.K : k.M, k.lda);
+    if (s != HIPBLAS_STATUS_SUCCESS) return s;
+    s = hipblasLtMatrixLayoutCreate(&p.ld, k.d32 ? HIP_R_32F : HIP_R_16BF, k.N, k.M, k.ldd);
+    if (s != HIPBLAS_STATUS_SUCCESS) return s;
+    uint32_t epi = HIPBLASLT_EPILOGUE_DEFAULT;
+    switch (k.epi) {
+    case VAH_GEMM_EPI_NONE: break;
+    case VAH_GEMM_EPI_BIAS: epi = HIPBLASLT_EPILOGUE_BIAS; break;
+    case VAH_GEMM_EPI_BIAS_GELU_AUX: epi = HIPBLASLT_EPILOGUE_GELU_AUX_BIAS; break;
+    case VAH_GEMM_EPI_DGELU: epi = HIPBLASLT_EPILOGUE_DGELU; break;
+    case VAH_GEMM_EPI_BGRAD_A: epi = HIPBLASLT_EPILOGUE_BGRADB; break;      // our A is the second operand
+    default: return HIPBLAS_STATUS_INVALID_VALUE;
+    }
+    hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi));
+    if (c.bias) {
+        hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &c.bias, sizeof(c.bias));
+        const int32_t bt = k.bias32 ? HIP_R_32F : HIP_R_16BF;
+        hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt));
+    }
+    if (c.aux) {
+        hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE_AUX_POINTER, &c.aux, sizeof(c.aux));
+        hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE_AUX_LD, &c.ld_aux, sizeof(c.ld_aux));
+    }
+    return HIPBLAS_STATUS_SUCCESS;
+}
+
+hipblasStatus_t run(State &S, const Call &c, Problem &p, const hipblasLtMatmulAlgo_t &algo, size_t ws_need) {
+    if (ws_need > c.ws_bytes) return HIPBLAS_STATUS_ALLOC_FAILED;
+    const float alpha = 1.f, beta = 0.f;
+    // operands swapped: see the header comment
+    return hipblasLtMatmul(S.handle, p.desc, &alpha, c.B, p.la, c.A, p.lb, &beta, c.D, p.ld, c.D, p.ld, &algo,
+                           c.ws, c.ws_bytes, c.st);
+}
+
+// Time one candidate on the caller's stream (the output is simply overwritten).
+float time_algo(State &S, const Call &c, Problem &p, const hipblasLtMatmulAlgo_t &algo, size_t ws_need,
+                hipEvent_t e0, hipEvent_t e1, int reps) {
+    if (run(S, c, p, algo, ws_need) != HIPBLAS_STATUS_SUCCESS) return -1.f;      // warm-up + validity
+    if (hipEventRecord(e0, c.st) != hipSuccess) return -1.f;
+    for (int i = 0; i < reps; ++i)
+        if (run(S, c, p, algo, ws_need) != HIPBLAS_STATUS_SUCCESS) return -1.f;
+    if (hipEventRecord(e1, c.st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return -1.f;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.f;
+    return ms * 1000.f / reps;
+}
+
+hipblasStatus_t choose(State &S, const Call &c, Problem &p, Choice &out) {
+    std::vector<hipblasLtMatmulHeuristicResult_t> cand;
+    if (S.mode == 2) {
+        std::vector<hipblasLtMatmulHeuristicResult_t> all;
+        const Key &k = c.k;
+        hipblasStatus_t s = hipblaslt_ext::getAllAlgos(
+            S.handle, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, k.tb ? HIPBLAS_OP_T : HIPBLAS_OP_N,
+            k.ta ? HIPBLAS_OP_T : HIPBLAS_OP_N, HIP_R_16BF, HIP_R_16BF, k.d32 ? HIP_R_32F : HIP_R_16BF,
+            k.d32 ? HIP_R_32F : HIP_R_16BF, HIPBLAS_COMPUTE_32F, all);
+        if (s == HIPBLAS_STATUS_SUCCESS)
+            for (auto &r : all) {
+                size_t need = 0;
+                const float one = 1.f, zero = 0.f;
+                if (hipblaslt_ext::matmulIsAlgoSupported(S.handle, p.desc, &one, p.la, p.lb, &zero, p.ld, p.ld, r.algo,
+                                                         need) == HIPBLAS_STATUS_SUCCESS &&
+                    need <= c.ws_bytes) {
+                    r.workspaceSize = need;
+                    cand.push_back(r);
+                }
+            }
+    }
+    if (cand.empty()) {
+        hipblasLtMatmulPreference_t pref = nullptr;
+        hipblasStatus_t s = hipblasLtMatmulPreferenceCreate(&pref);
+        if (s != HIPBLAS_STATUS_SUCCESS) return s;
+        const uint64_t wsmax = c.ws_bytes;
+        hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsmax, sizeof(wsmax));
+        const int want = S.mode == 0 ? 1 : S.candidates;
+        cand.resize(want);
+        int got = 0;
+        s = hipblasLtMatmulAlgoGetHeuristic(S.handle, p.desc, p.la, p.lb, p.ld, p.ld, pref, want, cand.data(), &got);
+        hipblasLtMatmulPreferenceDestroy(pref);
+        if (s != HIPBLAS_STATUS_SUCCESS) return s;
+        cand.resize(std::max(got, 0));
+        if (cand.empty()) return HIPBLAS_STATUS_NOT_SUPPORTED;
+    }
+    if (cand.size() == 1 || S.mode == 0) {
+        out.algo = cand[0].algo;
+        out.workspace = cand[0].workspaceSize;
+        out.index = hipblaslt_ext::getIndexFromAlgo(out.algo);
+        out.resolved = true;
+        return HIPBLAS_STATUS_SUCCESS;
+    }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return HIPBLAS_STATUS_ALLOC_FAILED;
+    float best = -1.f;
+    size_t best_i = 0;
+    // coarse pass over everything, then a longer look at the best few
+    std::vector<std::pair<float, size_t>> timed;
+    for (size_t i = 0; i < cand.size(); ++i) {
+        const float us = time_algo(S, c, p, cand[i].algo, cand[i].workspaceSize, e0, e1, 2);
+        if (us > 0.f) timed.emplace_back(us, i);
+    }
+    std::sort(timed.begin(), timed.end());
+    for (size_t j = 0; j < std::min<size_t>(timed.size(), 4); ++j) {
+        const size_t i = timed[j].second;
+        const float us = time_algo(S, c, p, cand[i].algo, cand[i].workspaceSize, e0, e1, 8);
+        if (us > 0.f && (best < 0.f || us < best)) {
+            best = us;
+            best_i = i;
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (best < 0.f) return HIPBLAS_STATUS_EXECUTION_FAILED;
+    out.algo = cand[best_i].algo;
+    out.workspace = cand[best_i].workspaceSize;
+    out.index = hipblaslt_ext::getIndexFromAlgo(out.algo);
+    out.us = best;
+    out.resolved = true;
+    return HIPBLAS_STATUS_SUCCESS;
+}
+
+// An entry that came from text: look the algorithm up by index and make sure it fits this problem.
+bool resolve(State &S, const Call &c, Problem &p, Choice &ch) {
+    std::vector<int> idx{ch.index};
+    std::vector<hipblasLtMatmulHeuristicResult_t> res;
+    if (ch.index < 0 || hipblaslt_ext::getAlgosFromIndex(S.handle, idx, res) != HIPBLAS_STATUS_SUCCESS || res.empty())
+        return false;
+    size_t need = 0;
+    const float one = 1.f, zero = 0.f;
+    if (hipblaslt_ext::matmulIsAlgoSupported(S.handle, p.desc, &one, p.la, p.lb, &zero, p.ld, p.ld, res[0].algo, need) !=
+            HIPBLAS_STATUS_SUCCESS || need > c.ws_bytes)
+        return false;
+    ch.algo = res[0].algo;
+    ch.workspace = need;
+    ch.resolved = true;
+    return true;
+}
+
+}  // namespace
+}  // namespace vah
+
+extern "C" {
+
+int vah_gemm_set_tuning(int mode, int candidates) {
+    using namespace vah;
+    clear_error();
+    if (mode < 0 || mode > 2 || candidates < 1 || candidates > 4096) return fail(VAH_E_SHAPE, "vah_gemm_set_tuning: bad arguments");
+    State &S = state();
+    std::lock_guard<std::mutex> lock(S.mu);
+    S.mode = mode;
+    S.candidates = candidates;
+    return VAH_OK;
+}
+
+int vah_gemm_bf16(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
+                  const void *B, int64_t ldb, void *D, int64_t ldd, int d_is_f32, int epilogue, const void *bias,
+                  int bias_is_f32, void *aux, int64_t ld_aux, void *workspace, int64_t workspace_bytes,
+                  void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_gemm_bf16";
+    if (M < 0 || N < 0 || K < 0) return fail(VAH_E_SHAPE, "%s: negative dimension", fn);
+    if (M == 0 || N == 0) return VAH_OK;
+    if (K == 0) return fail(VAH_E_SHAPE, "%s: K = 0 (zero-fill the output instead)", fn);
+    if (!A || !B || !D) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N) || ldd < N) return fail(VAH_E_SHAPE, "%s: leading dimension too small", fn);
+    if (epilogue < VAH_GEMM_EPI_NONE || epilogue > VAH_GEMM_EPI_BGRAD_A) return fail(VAH_E_SHAPE, "%s: unknown epilogue", fn);
+    const bool wants_bias = epilogue == VAH_GEMM_EPI_BIAS || epilogue == VAH_GEMM_EPI_BIAS_GELU_AUX ||
+                            epilogue == VAH_GEMM_EPI_BGRAD_A;
+    const bool wants_aux = epilogue == VAH_GEMM_EPI_BIAS_GELU_AUX || epilogue == VAH_GEMM_EPI_DGELU;
+    if (wants_bias != (bias != nullptr) || wants_aux != (aux != nullptr)) return fail(VAH_E_NULL, "%s: bias / aux do not match the epilogue", fn);
+    if (workspace_bytes < 0 || (workspace_bytes > 0 && !workspace)) return fail(VAH_E_NULL, "%s: workspace", fn);
+
+    State &S = state();
+    std::lock_guard<std::mutex> lock(S.mu);
+    if (!S.handle) {
+        const hipblasStatus_t s = hipblasLtCreate(&S.handle);
+        if (s != HIPBLAS_STATUS_SUCCESS) return fail(VAH_E_UNSUPPORTED, "%s: hipblasLtCreate: %s", fn, status_name(s));
+    }
+    Call c{{trans_a ? 1 : 0, trans_b ? 1 : 0, d_is_f32 ? 1 : 0, epilogue, bias_is_f32 ? 1 : 0, M, N, K, lda, ldb, ldd},
+           A, B, bias, D, aux, ld_aux, workspace, (size_t)workspace_bytes, (hipStream_t)stream};
+    Problem p;
+    hipblasStatus_t s = make_problem(c, p);
+    if (s != HIPBLAS_STATUS_SUCCESS) return fail(VAH_E_UNSUPPORTED, "%s: descriptor: %s", fn, status_name(s));
+    LaunchScope scope("gemm_bf16", (M * K + K * N) * 2 + M * N * (d_is_f32 ? 4 : 2), c.st);
+    auto it = S.table.find(c.k);
+    if (it != S.table.end() && !it->second.resolved && !resolve(S, c, p, it->second)) {
+        S.table.erase(it);
+        it = S.table.end();
+    }
+    if (it == S.table.end()) {
+        Choice ch;
+        s = choose(S, c, p, ch);
+        if (s != HIPBLAS_STATUS_SUCCESS)
+            return fail(VAH_E_UNSUPPORTED, "%s: no algorithm for %lldx%lldx%lld ta=%d tb=%d f32=%d epi=%d: %s", fn,
+                        (long long)M, (long long)N, (long long)K, trans_a, trans_b, d_is_f32, epilogue, status_name(s));
+        it = S.table.emplace(c.k, ch).first;
+    }
+    s = run(S, c, p, it->second.algo, it->second.workspace);
+    if (s != HIPBLAS_STATUS_SUCCESS) return fail(VAH_E_UNSUPPORTED, "%s: hipblasLtMatmul: %s", fn, status_name(s));
+    return check_launch(fn);
+}
+
+// One line per problem: "ta tb d32 epi bias32 M N K lda ldb ldd index us".
+int64_t vah_gemm_table_dump(char *buf, int64_t cap) {
+    using namespace vah;
+    State &S = state();
+    std::lock_guard<std::mutex> lock(S.mu);
+    std::ostringstream os;
+    for (auto &kv : S.table) {
+        const Key &k = kv.first;
+        os << k.ta << ' ' << k.tb << ' ' << k.d32 << ' ' << k.epi << ' ' << k.bias32 << ' ' << k.M << ' ' << k.N << ' '
+           << k.K << ' ' << k.lda << ' ' << k.ldb << ' ' << k.ldd << ' ' << kv.second.index << ' ' << kv.second.us << '\n';
+    }
+    const std::string t = os.str();
+    if (buf && cap > 0) {
+        const size_t n = std::min<size_t>(t.size(), (size_t)cap - 1);
+        memcpy(buf, t.data(), n);
+        buf[n] = 0;
+    }
+    return (int64_t)t.size() + 1;
+}
+
+int vah_gemm_table_load(const char *text) {
+    using namespace vah;
+    clear_error();
+    if (!text) return fail(VAH_E_NULL, "vah_gemm_table_load: null text");
+    State &S = state();
+    std::lock_guard<std::mutex> lock(S.mu);
+    std::istringstream is(text);
+    std::string line;
+    int n = 0;
+    while (std::getline(is, line)) {
+        if (line.empty() || line[0] == '#') continue;
+        std::istringstream ls(line);
+        Key k;
+        Choice ch;
+        if (!(ls >> k.ta >> k.tb >> k.d32 >> k.epi >> k.bias32 >> k.M >> k.N >> k.K >> k.lda >> k.ldb >> k.ldd >> ch.index >> ch.us))
+            return fail(VAH_E_SHAPE, "vah_gemm_table_load: malformed line '%s'", line.c_str());
+        ch.resolved = false;
+        S.table[k] = ch;
+        ++n;
+    }
+    return n;
+}
+
+}  // extern "C"

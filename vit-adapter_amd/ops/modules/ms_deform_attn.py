@@ -20,6 +20,12 @@ from torch import nn
 
 from ..functions import MSDeformAttnFunction, MSDeformAttnFusedFunction, fused_supported
 
+try:        # fused nn.Linear (bf16 working copies, fp32 weight gradients) when the backbone package is there
+    from vitadapter.fused import linear as _linear
+except ImportError:                                                     # ops/ used on its own
+    def _linear(lin, x):
+        return lin(x)
+
 _SCHEDULES = {}
 
 
@@ -104,18 +110,18 @@ class MSDeformAttn(nn.Module):
         if self.validate_shapes:
             assert int((input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum()) == S
 
-        value = self.value_proj(input_flatten)
+        value = _linear(self.value_proj, input_flatten)
         if input_padding_mask is not None:
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, S, M, value.shape[-1] // M)
 
-        offsets = self.sampling_offsets(query).view(N, Lq, M, L, P, 2)
-        logits = self.attention_weights(query).view(N, Lq, M, L * P)
+        offsets = _linear(self.sampling_offsets, query).view(N, Lq, M, L, P, 2)
+        logits = _linear(self.attention_weights, query).view(N, Lq, M, L * P)
         if fused_supported(value, offsets, logits, reference_points, L, P):
             # softmax + location arithmetic + gather in one kernel (csrc/msda_fused.hip)
             out = MSDeformAttnFusedFunction.apply(value, input_spatial_shapes, input_level_start_index,
                                                   offsets, logits, reference_points)
-            return self.output_proj(out)
+            return _linear(self.output_proj, out)
         weights = F.softmax(logits, -1).view(N, Lq, M, L, P)
 
         if reference_points.shape[-1] == 2:
@@ -130,4 +136,4 @@ class MSDeformAttn(nn.Module):
         with MSDA.query_schedule(schedule_for(reference_points, input_spatial_shapes)):
             out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
                                              loc, weights, self.im2col_step)
-        return self.output_proj(out)
+        return _linear(self.output_proj, out)

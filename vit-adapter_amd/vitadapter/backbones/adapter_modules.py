@@ -99,8 +99,8 @@ class ConvFFN(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x, H, W):
-        x = self.drop(self.act(self.dwconv(self.fc1(x), H, W)))
-        return self.drop(self.fc2(x))
+        x = self.drop(self.act(self.dwconv(fused.linear(self.fc1, x), H, W)))
+        return self.drop(fused.linear(self.fc2, x))
 
 
 class Extractor(nn.Module):
@@ -123,13 +123,13 @@ class Extractor(nn.Module):
 
     def forward(self, query, reference_points, feat, spatial_shapes, level_start_index, H, W):
         def body(query, feat):
-            attn = self.attn(fused.layer_norm(self.query_norm, query), reference_points,
-                             fused.layer_norm(self.feat_norm, feat), spatial_shapes,
+            query, qn = fused.layer_norm_keep(self.query_norm, query)
+            attn = self.attn(qn, reference_points, fused.layer_norm(self.feat_norm, feat), spatial_shapes,
                              level_start_index, None)
             query = fused.residual(query, attn)
             if self.with_cffn:
-                query = fused.residual(query, self.ffn(fused.layer_norm(self.ffn_norm, query), H, W),
-                                       None, self.drop_path)
+                query, qn = fused.layer_norm_keep(self.ffn_norm, query)
+                query = fused.residual(query, self.ffn(qn, H, W), None, self.drop_path)
             return query
 
         if self.with_cp and query.requires_grad:
@@ -152,8 +152,8 @@ class Injector(nn.Module):
 
     def forward(self, query, reference_points, feat, spatial_shapes, level_start_index):
         def body(query, feat):
-            attn = self.attn(fused.layer_norm(self.query_norm, query), reference_points,
-                             fused.layer_norm(self.feat_norm, feat), spatial_shapes,
+            query, qn = fused.layer_norm_keep(self.query_norm, query)
+            attn = self.attn(qn, reference_points, fused.layer_norm(self.feat_norm, feat), spatial_shapes,
                              level_start_index, None)
             return fused.residual(query, attn, self.gamma)
 

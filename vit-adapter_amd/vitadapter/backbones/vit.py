@@ -53,7 +53,7 @@ class Mlp(nn.Module):
         self.drop = nn.Dropout(drop)
 
     def forward(self, x):
-        return self.drop(self.fc2(self.drop(self.act(self.fc1(x)))))
+        return self.drop(fused.linear(self.fc2, self.drop(self.act(fused.linear(self.fc1, x)))))
 
 
 class PatchEmbed(nn.Module):
@@ -94,9 +94,9 @@ class Attention(nn.Module):
 
     def forward(self, x, H, W):
         B, N, C = x.shape
-        qkv = self.qkv(x).view(B, N, 3, self.num_heads, C // self.num_heads)
+        qkv = fused.linear(self.qkv, x).view(B, N, 3, self.num_heads, C // self.num_heads)
         out = kernels.attention(qkv, self.scale, self.attn_drop.p if self.training else 0.)
-        return self.proj_drop(self.proj(out.reshape(B, N, C)))
+        return self.proj_drop(fused.linear(self.proj, out.reshape(B, N, C)))
 
 
 class WindowedAttention(nn.Module):
@@ -119,12 +119,12 @@ class WindowedAttention(nn.Module):
         ws = self.window_size
         Hp, Wp = math.ceil(H / ws) * ws, math.ceil(W / ws) * ws
         nh, nw = Hp // ws, Wp // ws
-        qkv = self.qkv(x)
+        qkv = fused.linear(self.qkv, x)
         if self.pad_mode == 'constant':
-            fused = kernels.window_attention(qkv.view(B, N, 3, self.num_heads, C // self.num_heads),
-                                             self.scale, H, W, ws, self.attn_drop.p if self.training else 0.)
-            if fused is not None:      # windows cut inside the kernels: no pad / partition copies
-                return self.proj_drop(self.proj(fused.reshape(B, N, C)))
+            win = kernels.window_attention(qkv.view(B, N, 3, self.num_heads, C // self.num_heads),
+                                           self.scale, H, W, ws, self.attn_drop.p if self.training else 0.)
+            if win is not None:      # windows cut inside the kernels: no pad / partition copies
+                return self.proj_drop(fused.linear(self.proj, win.reshape(B, N, C)))
         qkv = qkv.view(B, H, W, 3 * C)
         if Hp != H or Wp != W:
             if self.pad_mode == 'constant':
@@ -139,7 +139,7 @@ class WindowedAttention(nn.Module):
         out = out.reshape(B, nh, nw, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)
         if Hp != H or Wp != W:
             out = out[:, :H, :W, :]
-        return self.proj_drop(self.proj(out.reshape(B, N, C)))
+        return self.proj_drop(fused.linear(self.proj, out.reshape(B, N, C)))
 
 
 class LayerNorm(nn.Module):
@@ -222,10 +222,10 @@ class Block(nn.Module):
     def _body(self, x, H, W):
         # x + drop_path(gamma1 * attn(norm1(x))), x + drop_path(gamma2 * mlp(norm2(x)))
         # (ref base/vit.py:301-306); fused.* fall back to exactly that expression off the bf16 path
-        a = self.attn(fused.layer_norm(self.norm1, x), H, W)
-        x = fused.residual(x, a, self.gamma1 if self.layer_scale else None, self.drop_path)
-        f = self.mlp(fused.layer_norm(self.norm2, x))
-        x = fused.residual(x, f, self.gamma2 if self.layer_scale else None, self.drop_path)
+        x, h = fused.layer_norm_keep(self.norm1, x)
+        x = fused.residual(x, self.attn(h, H, W), self.gamma1 if self.layer_scale else None, self.drop_path)
+        x, h = fused.layer_norm_keep(self.norm2, x)
+        x = fused.residual(x, self.mlp(h), self.gamma2 if self.layer_scale else None, self.drop_path)
         if self.use_residual:
             B, N, C = x.shape
             y = self.residual(x.reshape(B, H, W, C).permute(0, 3, 1, 2))

@@ -16,6 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from ops.modules import MSDeformAttn
 
+from .. import fused
 from .adapter_modules import InteractionBlock, SpatialPriorModule, deform_inputs
 from .vit import TIMMVisionTransformer
 
@@ -116,6 +117,7 @@ class ViTAdapter(TIMMVisionTransformer):
         return c2 + self.level_embed[0], c3 + self.level_embed[1], c4 + self.level_embed[2]
 
     def forward(self, x):
+        fused.refresh_linear_copies(self)      # bf16 copies of the Linear weights: one launch per step
         deform_inputs1, deform_inputs2 = deform_inputs(x)
 
         c1, c2, c3, c4 = self.spm(x)

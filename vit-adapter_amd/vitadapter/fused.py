@@ -5,12 +5,14 @@ it takes the fused HIP path when the tensors are what bf16 autocast produces on 
 residual stream, bf16 branch outputs) and otherwise evaluates the same expression with torch ops
 (fp32 runs, CPU host-logic tests).
 """
+import os
+
 import torch
 import torch.nn.functional as F
 
 import _vah
 
-ENABLED = {'layer_norm': True, 'residual': True, 'dwconv': True}
+ENABLED = {'layer_norm': True, 'residual': True, 'dwconv': True, 'linear': True}
 
 
 def _stream(t):
@@ -28,10 +30,16 @@ def _bf16_autocast():
 
 
 class _LayerNormBF16(torch.autograd.Function):
+    """LayerNorm of the fp32 residual stream with bf16 output.  With ``keep`` the stream itself is
+    returned next to the normalised copy, so the gradient of the residual branch and the LayerNorm
+    gradient meet in ONE backward call and are summed inside the kernel (otherwise autograd adds
+    them with a separate fp32 add per LayerNorm)."""
+
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, keep):
         C = x.shape[-1]
-        x2 = x.contiguous().view(-1, C)
+        xc = x.contiguous()
+        x2 = xc.view(-1, C)
         rows = x2.shape[0]
         y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
@@ -43,31 +51,220 @@ class _LayerNormBF16(torch.autograd.Function):
                 mean.data_ptr(), rstd.data_ptr(), _stream(x)), 'layernorm_fwd')
         ctx.save_for_backward(x2, w, mean, rstd)
         ctx.shape = x.shape
+        ctx.set_materialize_grads(False)
+        if keep:
+            return xc, y
         return y
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, *grads):
+        gres, g = grads if len(grads) == 2 else (None, grads[0])
         x2, w, mean, rstd = ctx.saved_tensors
         rows, C = x2.shape
+        if g is None:                      # the normalised copy was not used
+            return (gres, None, None, None, None)
         g = g.contiguous().to(torch.bfloat16)
+        if gres is not None:
+            gres = gres.contiguous().float()
         dx = torch.empty_like(x2)
         dwb = torch.empty(2, C, dtype=torch.float32, device=x2.device)
         ws = _scratch(2 * C, x2.device)
         with torch.cuda.device(x2.device):
             _vah.check(_vah.lib.vah_layernorm_bwd_f32_bf16(
-                x2.data_ptr(), g.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(), rows, C,
+                x2.data_ptr(), g.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                gres.data_ptr() if gres is not None else None, rows, C,
                 dx.data_ptr(), dwb[0].data_ptr(), dwb[1].data_ptr(), ws.data_ptr(), _stream(x2)),
                 'layernorm_bwd')
-        return dx.view(ctx.shape), dwb[0], dwb[1], None
+        return dx.view(ctx.shape), dwb[0], dwb[1], None, None
+
+
+def _ln_fusable(norm, x):
+    return (ENABLED['layer_norm'] and x.is_cuda and x.dtype == torch.float32 and _bf16_autocast()
+            and isinstance(norm, torch.nn.LayerNorm) and norm.elementwise_affine
+            and x.shape[-1] % 4 == 0 and x.shape[-1] <= 2048 and x.numel() > 0)
 
 
 def layer_norm(norm, x):
     """``norm(x)`` for an nn.LayerNorm; bf16 output when the consumer is a bf16 GEMM (autocast)."""
-    if (ENABLED['layer_norm'] and x.is_cuda and x.dtype == torch.float32 and _bf16_autocast()
-            and isinstance(norm, torch.nn.LayerNorm) and norm.elementwise_affine
-            and x.shape[-1] % 4 == 0 and x.shape[-1] <= 2048 and x.numel() > 0):
-        return _LayerNormBF16.apply(x, norm.weight, norm.bias, norm.eps)
+    if _ln_fusable(norm, x):
+        return _LayerNormBF16.apply(x, norm.weight, norm.bias, norm.eps, False)
     return norm(x)
+
+
+def layer_norm_keep(norm, x):
+    """``(x, norm(x))`` for the pattern ``x + branch(norm(x))``: use the returned ``x`` for the
+    residual update so both gradients of ``x`` are summed inside the LayerNorm backward kernel."""
+    if _ln_fusable(norm, x):
+        return _LayerNormBF16.apply(x, norm.weight, norm.bias, norm.eps, True)
+    return x, norm(x)
+
+
+# ---------------------------------------------------------------------------------------
+# nn.Linear under bf16 autocast
+# ---------------------------------------------------------------------------------------
+class _Bf16Copies:
+    """bf16 working copies of fp32 parameters.  autocast makes the same copies, but one tiny cast
+    kernel per parameter per step (and one more per gradient on the way back); here every copy of
+    a model is refreshed by one multi-tensor launch after the optimizer has stepped
+    (``refresh``), and a parameter that was missed is refreshed on use."""
+
+    def __init__(self):
+        self.entries = {}          # id(param) -> [weakref(param), copy, version, data_ptr]
+
+    def get(self, p):
+        e = self.entries.get(id(p))
+        if e is None or e[0]() is not p or e[3] != p.data_ptr() or e[1].device != p.device:
+            import weakref
+            e = [weakref.ref(p), p.detach().to(torch.bfloat16), p._version, p.data_ptr()]
+            self.entries[id(p)] = e
+            if len(self.entries) > 4096:           # drop entries of collected parameters
+                self.entries = {k: v for k, v in self.entries.items() if v[0]() is not None}
+        elif e[2] != p._version:
+            e[1].copy_(p.detach())
+            e[2] = p._version
+        return e[1]
+
+    def refresh(self, params):
+        dst, src = [], []
+        for p in params:
+            e = self.entries.get(id(p))
+            if e is None or e[0]() is not p or e[3] != p.data_ptr() or e[1].device != p.device:
+                self.get(p)
+            elif e[2] != p._version:
+                dst.append(e[1])
+                src.append(p.detach())
+                e[2] = p._version
+        if dst:
+            torch._foreach_copy_(dst, src)
+
+
+BF16_COPIES = _Bf16Copies()
+
+
+def refresh_linear_copies(module):
+    """Call once per forward of a model: one multi-tensor cast refreshes the bf16 copies of all
+    its nn.Linear parameters that changed since the last call."""
+    if not (ENABLED['linear'] and _bf16_autocast()):
+        return
+    params = module.__dict__.get('_vah_linear_params')
+    if params is None:
+        params = [p for m in module.modules() if isinstance(m, torch.nn.Linear)
+                  for p in (m.weight, m.bias) if p is not None and p.dtype == torch.float32]
+        module.__dict__['_vah_linear_params'] = params
+    if params and params[0].is_cuda:
+        BF16_COPIES.refresh(params)
+
+
+_GEMM_WS_BYTES = 32 << 20
+WGRAD_F32 = os.environ.get('VAH_LINEAR_WGRAD', 'f32') == 'f32'
+GEMM_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuning', 'gemm_table_mi355x.txt')
+
+
+def _configure_gemm():
+    """VAH_GEMM_TUNING = mode[,candidates] (0 first heuristic answer, 1 time the heuristic
+    candidates [default], 2 time every algorithm);  VAH_GEMM_TABLE = path of a tuned table to load
+    ('' = none; default: the committed table);  VAH_GEMM_TABLE_DUMP = path to write the table to
+    at exit."""
+    spec = os.environ.get('VAH_GEMM_TUNING')
+    if spec:
+        parts = [int(v) for v in spec.split(',')]
+        _vah.check(_vah.lib.vah_gemm_set_tuning(parts[0], parts[1] if len(parts) > 1 else 32), 'gemm_set_tuning')
+    path = os.environ.get('VAH_GEMM_TABLE', GEMM_TABLE)
+    if path and os.path.exists(path):
+        _vah.gemm_table_load(open(path).read())
+    dump = os.environ.get('VAH_GEMM_TABLE_DUMP')
+    if dump:
+        import atexit
+        atexit.register(lambda: open(dump, 'w').write(_vah.gemm_table_dump()))
+
+
+_configure_gemm()
+
+
+def gemm_bf16(a, b, trans_a=False, trans_b=False, out_dtype=torch.bfloat16, bias=None,
+              epilogue=None, aux=None):
+    """op(a) @ op(b) for contiguous 2-D bf16 matrices on the tuned hipBLASLt dispatcher
+    (csrc/gemm.hip); fp32 accumulation, bf16 or fp32 result."""
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    N = b.shape[0] if trans_b else b.shape[1]
+    assert (b.shape[1] if trans_b else b.shape[0]) == K and a.is_contiguous() and b.is_contiguous()
+    d = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    if M == 0 or N == 0:
+        return d
+    if K == 0:
+        return d.zero_()
+    ws = torch.empty(_GEMM_WS_BYTES, dtype=torch.uint8, device=a.device)
+    if epilogue is None:
+        epilogue = _vah.GEMM_EPI_BIAS if bias is not None else _vah.GEMM_EPI_NONE
+    with torch.cuda.device(a.device):
+        _vah.check(_vah.lib.vah_gemm_bf16(
+            int(trans_a), int(trans_b), M, N, K, a.data_ptr(), a.shape[1], b.data_ptr(), b.shape[1],
+            d.data_ptr(), N, int(out_dtype == torch.float32), epilogue,
+            bias.data_ptr() if bias is not None else None,
+            int(bias is not None and bias.dtype == torch.float32),
+            aux.data_ptr() if aux is not None else None, aux.shape[1] if aux is not None else 0,
+            ws.data_ptr(), _GEMM_WS_BYTES, _stream(a)), 'gemm_bf16')
+    return d
+
+
+class _LinearBF16(torch.autograd.Function):
+    """y = x W^T + b with bf16 operands and fp32 accumulation (what autocast makes of F.linear).
+    Backward: dX in bf16, dW straight into fp32 from the GEMM (no bf16 rounding, no cast kernel),
+    db by the column-sum kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        if x2.dtype != torch.bfloat16:
+            x2 = x2.to(torch.bfloat16)
+        x2 = x2.contiguous()
+        wb = BF16_COPIES.get(weight)
+        y = gemm_bf16(x2, wb, trans_b=True, bias=bias.detach() if bias is not None else None)
+        ctx.save_for_backward(x2)
+        ctx.wb = wb
+        ctx.has_bias = bias is not None
+        ctx.in_shape = x.shape
+        ctx.in_dtype = x.dtype
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        (x2,) = ctx.saved_tensors
+        wb = ctx.wb
+        N = wb.shape[0]
+        g2 = g.reshape(-1, N)
+        if g2.dtype != torch.bfloat16:
+            g2 = g2.to(torch.bfloat16)
+        g2 = g2.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm_bf16(g2, wb).view(ctx.in_shape)
+            if gx.dtype != ctx.in_dtype:
+                gx = gx.to(ctx.in_dtype)
+        if ctx.needs_input_grad[1]:
+            if WGRAD_F32:
+                gw = gemm_bf16(g2, x2, trans_a=True, out_dtype=torch.float32)
+            else:
+                gw = gemm_bf16(g2, x2, trans_a=True).float()
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = torch.empty(N, dtype=torch.float32, device=g2.device)
+            ws = _scratch(N, g2.device)
+            with torch.cuda.device(g2.device):
+                _vah.check(_vah.lib.vah_colsum_bf16(g2.data_ptr(), g2.shape[0], N, gb.data_ptr(),
+                                                    ws.data_ptr(), _stream(g2)), 'colsum')
+        return gx, gw, gb
+
+
+def linear(lin, x):
+    """``lin(x)`` for an nn.Linear (reference: every nn.Linear of base/vit.py, adapter_modules.py
+    and ms_deform_attn.py)."""
+    w = lin.weight
+    if (ENABLED['linear'] and x.is_cuda and _bf16_autocast() and w.dtype == torch.float32
+            and x.dtype in (torch.bfloat16, torch.float32) and w.shape[0] % 8 == 0
+            and w.shape[1] % 8 == 0 and x.numel() > 0 and type(lin) is torch.nn.Linear):
+        return _LinearBF16.apply(x, w, lin.bias)
+    return lin(x)
 
 
 class _ScaleResidual(torch.autograd.Function):
