@@ -238,15 +238,40 @@ int vah_layernorm_bwd_f32_bf16(const float *x, const void *g_bf16, const float *
  * (what autograd computes as grad_output.sum(0)); ws K = C. */
 int vah_colsum_bf16(const void *g_bf16, int64_t rows, int64_t C, float *out, float *ws, void *stream);
 
+/* ---- output tail: BatchNorm(a + b + bilinear_upsample_s(x)) (csrc/tail_ops.hip) ---------------
+ * Reference: vit_adapter.py:106-127 (seg) / :101-120 (det):  c1 = up(c2) + c1;  c1 = c1 +
+ * F.interpolate(x1, scale_factor=4, mode='bilinear', align_corners=False);  f1 = norm1(c1)  and the
+ * same for the stride-8 / stride-16 maps.  The sum is never stored: every pass recomputes it.
+ * a (N, C, H, W) bf16 or fp32; b optional, same shape; x optional fp32 (N, C, H/s, W/s),
+ * s in {1, 2, 4, 8}; W % 4 == 0 and (W/s) % 4 == 0.
+ *   stats:      sums[0:C] = sum t, sums[C:2C] = sum t^2 over (N, H, W)          (ws: vah_bn_tail_ws_floats(C))
+ *   apply:      y = (t - mean) * rstd * gamma + beta          (fp32; gamma / beta may be NULL)
+ *   bwd_stats:  sums[0:C] = sum dy, sums[C:2C] = sum dy * xhat
+ *   bwd_apply:  dt = gamma * rstd * (dy - mdy - xhat * mdyx);  da, db <- dt (own dtypes, may be NULL);
+ *               dxlo += upsample^T(dt)  (fp32, zero-filled by the caller; NULL to skip)
+ * The caller owns the statistics between the passes (SyncBatchNorm all-reduces them there). */
+int64_t vah_bn_tail_ws_floats(int64_t C);
+int vah_bn_tail_stats(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale,
+                      int64_t N, int64_t C, int64_t H, int64_t W, float *sums, float *ws, void *stream);
+int vah_bn_tail_apply(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale,
+                      int64_t N, int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd,
+                      const float *gamma, const float *beta, float *y, void *stream);
+int vah_bn_tail_bwd_stats(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale,
+                          int64_t N, int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd,
+                          const float *dy, float *sums, float *ws, void *stream);
+int vah_bn_tail_bwd_apply(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale,
+                          int64_t N, int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd,
+                          const float *gamma, const float *dy, const float *mdy, const float *mdyx,
+                          void *da, void *db, float *dxlo, void *stream);
+
 /* ---- bf16 GEMMs of the Linear layers (csrc/gemm.hip) ----------------------------------------
  * D (M x N, row-major, leading dimension ldd; bf16, or fp32 when d_is_f32) = op(A) op(B), bf16
  * operands, fp32 accumulation.  trans_a: A is stored (K x M) row-major and used transposed;
  * trans_b likewise (B stored (N x K)).  Replaces F.linear and its backward products
  * (torch addmm / mm on hipBLASLt): forward  y = x W^T + b   (trans_b = 1, EPI_BIAS),
  * input gradient  dx = g W   and weight gradient  dW = g^T x  (trans_a = 1, fp32 output).
- * Epilogues: BIAS adds bias[N] (bf16 or fp32); BIAS_GELU_AUX also stores the pre-activation in
- * aux (bf16, ld_aux) and applies GELU (tanh-free erf form of hipBLASLt); DGELU multiplies by
- * GELU'(aux); BGRAD_A additionally writes sum over K of A (the bias gradient when A = g^T) to bias.
+ * Epilogue BIAS adds bias[N] (bf16 or fp32).  (hipBLASLt's GELU / bias-gradient epilogues were
+ * measured on gfx950 and are slower than the separate kernels or unsupported for these types.)
  * The library times the hipBLASLt candidates of every new problem once on the caller's stream
  * (vah_gemm_set_tuning: mode 0 = first heuristic answer, 1 = time `candidates` heuristic answers
  * [default, 32], 2 = time every algorithm of the library) and caches the winner; the cache can be
@@ -254,14 +279,10 @@ int vah_colsum_bf16(const void *g_bf16, int64_t rows, int64_t C, float *out, flo
  * workspace: caller-provided scratch (32 MiB is ample), private to the stream. */
 #define VAH_GEMM_EPI_NONE 0
 #define VAH_GEMM_EPI_BIAS 1
-#define VAH_GEMM_EPI_BIAS_GELU_AUX 2
-#define VAH_GEMM_EPI_DGELU 3
-#define VAH_GEMM_EPI_BGRAD_A 4
 int vah_gemm_set_tuning(int mode, int candidates);
 int vah_gemm_bf16(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
                   const void *B, int64_t ldb, void *D, int64_t ldd, int d_is_f32, int epilogue,
-                  const void *bias, int bias_is_f32, void *aux, int64_t ld_aux, void *workspace,
-                  int64_t workspace_bytes, void *stream);
+                  const void *bias, int bias_is_f32, void *workspace, int64_t workspace_bytes, void *stream);
 int64_t vah_gemm_table_dump(char *buf, int64_t cap);   /* returns the size needed (incl. NUL) */
 int vah_gemm_table_load(const char *text);             /* returns the number of entries, < 0 on error */
 /* y = x + s[b] * gamma[c] * z   (x, y fp32 (batch, rows_per_batch, C); z bf16; gamma (C) or NULL;

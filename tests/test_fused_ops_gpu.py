@@ -253,3 +253,57 @@ def test_gemm_table_roundtrip():
     assert torch.equal(fused.gemm_bf16(a, b), d)   # entries are re-resolved from their index
     with pytest.raises(RuntimeError):
         _vah.gemm_table_load('not a table line')
+
+
+@pytest.mark.parametrize('N,C,H,W,scale,with_b,a_bf16,training', [
+    (2, 24, 64, 64, 4, True, True, True),      # norm1: up(c2) + c1 + interp(x, 4)
+    (2, 16, 32, 48, 2, False, False, True),    # norm2: c2 + interp(x, 2)
+    (1, 8, 16, 16, 1, False, False, True),     # norm3: c3 + x
+    (2, 8, 96, 32, 4, True, True, False),      # eval: running statistics
+    (1, 4, 128, 256, 8, False, True, True),    # several row tiles per plane
+    (3, 5, 40, 24, 2, True, False, True),
+])
+def test_bn_tail_matches_reference_expression(N, C, H, W, scale, with_b, a_bf16, training):
+    """fused.bn_tail = norm(a + b + F.interpolate(x, scale)) (vit_adapter.py:106-127) in fp32 on the
+    same (bf16-valued) operands: outputs, all five gradients and the running statistics."""
+    from vitadapter import fused
+    torch.manual_seed(7)
+    dt = torch.bfloat16 if a_bf16 else torch.float32
+    a = torch.randn(N, C, H, W, device='cuda').to(dt).requires_grad_(True)
+    b = (torch.randn(N, C, H, W, device='cuda') + 0.5).to(torch.bfloat16).requires_grad_(True) if with_b else None
+    x = torch.randn(N, C, H // scale, W // scale, device='cuda', requires_grad=True)
+    bn = torch.nn.BatchNorm2d(C).cuda()
+    ref_bn = torch.nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        bn.weight.normal_(1, 0.3)
+        bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(0, 0.5)
+        bn.running_var.uniform_(0.5, 2)
+    ref_bn.load_state_dict(bn.state_dict())
+    bn.train(training)
+    ref_bn.train(training)
+    g = torch.randn(N, C, H, W, device='cuda')
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        y = fused.bn_tail(bn, a, b, x, scale)
+    assert y.dtype == torch.float32
+    y.backward(g)
+    got = dict(a=a.grad.clone(), x=x.grad.clone(), w=bn.weight.grad.clone(), bias=bn.bias.grad.clone())
+    if with_b:
+        got['b'] = b.grad.clone()
+    a2 = a.detach().float().requires_grad_(True)
+    b2 = b.detach().float().requires_grad_(True) if with_b else None
+    x2 = x.detach().clone().requires_grad_(True)
+    t = a2 + b2 if with_b else a2
+    t = t + (x2 if scale == 1 else F.interpolate(x2, scale_factor=scale, mode='bilinear', align_corners=False))
+    yr = ref_bn(t)
+    yr.backward(g)
+    _close(y, yr, 2e-5, 'y')
+    _close(got['a'], a2.grad, 1e-2 if a_bf16 else 2e-5, 'da')
+    if with_b:
+        _close(got['b'], b2.grad, 1e-2, 'db')
+    _close(got['x'], x2.grad, 5e-5, 'dx')
+    _close(got['w'], ref_bn.weight.grad, 1e-4, 'dweight')
+    _close(got['bias'], ref_bn.bias.grad, 1e-4, 'dbias')
+    _close(bn.running_mean, ref_bn.running_mean, 1e-5, 'running_mean')
+    _close(bn.running_var, ref_bn.running_var, 1e-5, 'running_var')
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked)

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -76,10 +76,17 @@ lib.vah_colsum_bf16.argtypes = [_p, _i64, _i64, _p, _p, _p]
 _int = ctypes.c_int
 lib.vah_gemm_set_tuning.argtypes = [_int, _int]
 lib.vah_gemm_bf16.argtypes = [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _int, _int, _p, _int,
-                              _p, _i64, _p, _i64, _p]
+                              _p, _i64, _p]
 lib.vah_gemm_table_dump.argtypes = [ctypes.c_char_p, _i64]
 lib.vah_gemm_table_dump.restype = _i64
 lib.vah_gemm_table_load.argtypes = [ctypes.c_char_p]
+_tail_in = [_p, _int, _p, _int, _p, _int, _i64, _i64, _i64, _i64]
+lib.vah_bn_tail_ws_floats.argtypes = [_i64]
+lib.vah_bn_tail_ws_floats.restype = _i64
+lib.vah_bn_tail_stats.argtypes = _tail_in + [_p, _p, _p]
+lib.vah_bn_tail_apply.argtypes = _tail_in + [_p, _p, _p, _p, _p, _p]
+lib.vah_bn_tail_bwd_stats.argtypes = _tail_in + [_p, _p, _p, _p, _p, _p]
+lib.vah_bn_tail_bwd_apply.argtypes = _tail_in + [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p]
 lib.vah_reduce_ws_floats.argtypes = [_i64]
 lib.vah_reduce_ws_floats.restype = _i64
 lib.vah_scale_residual_fwd.argtypes = [_p, _p, _p, _p, _i64, _i64, _i64, _p, _p]
@@ -88,7 +95,8 @@ lib.vah_dwconv3x3_tokens_bf16.argtypes = [_p, _p, _p, _i64, _i64, _i64, _i64, ct
 lib.vah_dwconv3x3_tokens_wgrad_bf16.argtypes = [_p, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _p]
 for _n in ('vah_layernorm_fwd_f32_bf16', 'vah_layernorm_bwd_f32_bf16', 'vah_scale_residual_fwd',
            'vah_scale_residual_bwd', 'vah_dwconv3x3_tokens_bf16', 'vah_dwconv3x3_tokens_wgrad_bf16',
-           'vah_colsum_bf16', 'vah_gemm_set_tuning', 'vah_gemm_bf16', 'vah_gemm_table_load'):
+           'vah_colsum_bf16', 'vah_gemm_set_tuning', 'vah_gemm_bf16', 'vah_gemm_table_load',
+           'vah_bn_tail_stats', 'vah_bn_tail_apply', 'vah_bn_tail_bwd_stats', 'vah_bn_tail_bwd_apply'):
     getattr(lib, _n).restype = ctypes.c_int
 
 if lib.vah_abi_version() != ABI_VERSION:
@@ -107,6 +115,7 @@ EXPORTS = (
     'vah_reduce_ws_floats', 'vah_layernorm_fwd_f32_bf16', 'vah_layernorm_bwd_f32_bf16', 'vah_scale_residual_fwd',
     'vah_scale_residual_bwd', 'vah_dwconv3x3_tokens_bf16', 'vah_dwconv3x3_tokens_wgrad_bf16', 'vah_colsum_bf16',
     'vah_gemm_set_tuning', 'vah_gemm_bf16', 'vah_gemm_table_dump', 'vah_gemm_table_load',
+    'vah_bn_tail_ws_floats', 'vah_bn_tail_stats', 'vah_bn_tail_apply', 'vah_bn_tail_bwd_stats', 'vah_bn_tail_bwd_apply',
 )
 
 
@@ -133,7 +142,7 @@ def prof_report():
     return out
 
 
-GEMM_EPI_NONE, GEMM_EPI_BIAS, GEMM_EPI_BIAS_GELU_AUX, GEMM_EPI_DGELU, GEMM_EPI_BGRAD_A = range(5)
+GEMM_EPI_NONE, GEMM_EPI_BIAS = 0, 1
 
 
 def gemm_table_dump():

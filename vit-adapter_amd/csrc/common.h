@@ -53,6 +53,14 @@ __device__ __forceinline__ float dpp_sum32_hi(float x) {
     x = dpp_sum16(x);
     return x + dpp_mov<0x142, 0xA>(x);
 }
+
+// Sum over the 64 lanes of the wave, valid in every lane.
+__device__ __forceinline__ float wave_sum(float x) {
+    x = dpp_sum16(x);
+    x += __shfl_xor(x, 16, 64);
+    x += __shfl_xor(x, 32, 64);
+    return x;
+}
 #endif
 
 }  // namespace vah

@@ -24,13 +24,6 @@ namespace {
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 
-__device__ __forceinline__ float wave_sum(float x) {
-    x = dpp_sum16(x);
-    x += __shfl_xor(x, 16, 64);
-    x += __shfl_xor(x, 32, 64);
-    return x;
-}
-
 constexpr int kMaxVecAll = 8;    // float4 groups per lane: C <= 64 * 4 * 8 = 2048 (template NV <= 8)
 
 // ---------------------------------------------------------------------------------------

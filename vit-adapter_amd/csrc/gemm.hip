@@ -89,8 +89,7 @@ struct Problem {
 struct Call {
     Key k;
     const void *A, *B, *bias;
-    void *D, *aux;
-    int64_t ld_aux;
+    void *D;
     void *ws;
     size_t ws_bytes;
     hipStream_t st;
@@ -116,9 +115,6 @@ hipblasStatus_t make_problem(const Call &c, Problem &p) {
     switch (k.epi) {
     case VAH_GEMM_EPI_NONE: break;
     case VAH_GEMM_EPI_BIAS: epi = HIPBLASLT_EPILOGUE_BIAS; break;
-    case VAH_GEMM_EPI_BIAS_GELU_AUX: epi = HIPBLASLT_EPILOGUE_GELU_AUX_BIAS; break;
-    case VAH_GEMM_EPI_DGELU: epi = HIPBLASLT_EPILOGUE_DGELU; break;
-    case VAH_GEMM_EPI_BGRAD_A: epi = HIPBLASLT_EPILOGUE_BGRADB; break;      // our A is the second operand
     default: return HIPBLAS_STATUS_INVALID_VALUE;
     }
     hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi));
@@ -126,10 +122,6 @@ hipblasStatus_t make_problem(const Call &c, Problem &p) {
         hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &c.bias, sizeof(c.bias));
         const int32_t bt = k.bias32 ? HIP_R_32F : HIP_R_16BF;
         hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt));
-    }
-    if (c.aux) {
-        hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE_AUX_POINTER, &c.aux, sizeof(c.aux));
-        hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE_AUX_LD, &c.ld_aux, sizeof(c.ld_aux));
     }
     return HIPBLAS_STATUS_SUCCESS;
 }
@@ -263,8 +255,7 @@ int vah_gemm_set_tuning(int mode, int candidates) {
 
 int vah_gemm_bf16(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
                   const void *B, int64_t ldb, void *D, int64_t ldd, int d_is_f32, int epilogue, const void *bias,
-                  int bias_is_f32, void *aux, int64_t ld_aux, void *workspace, int64_t workspace_bytes,
-                  void *stream) {
+                  int bias_is_f32, void *workspace, int64_t workspace_bytes, void *stream) {
     using namespace vah;
     clear_error();
     const char *fn = "vah_gemm_bf16";
@@ -273,11 +264,8 @@ int vah_gemm_bf16(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, con
     if (K == 0) return fail(VAH_E_SHAPE, "%s: K = 0 (zero-fill the output instead)", fn);
     if (!A || !B || !D) return fail(VAH_E_NULL, "%s: null pointer", fn);
     if (lda < (trans_a ? M : K) || ldb < (trans_b ? K : N) || ldd < N) return fail(VAH_E_SHAPE, "%s: leading dimension too small", fn);
-    if (epilogue < VAH_GEMM_EPI_NONE || epilogue > VAH_GEMM_EPI_BGRAD_A) return fail(VAH_E_SHAPE, "%s: unknown epilogue", fn);
-    const bool wants_bias = epilogue == VAH_GEMM_EPI_BIAS || epilogue == VAH_GEMM_EPI_BIAS_GELU_AUX ||
-                            epilogue == VAH_GEMM_EPI_BGRAD_A;
-    const bool wants_aux = epilogue == VAH_GEMM_EPI_BIAS_GELU_AUX || epilogue == VAH_GEMM_EPI_DGELU;
-    if (wants_bias != (bias != nullptr) || wants_aux != (aux != nullptr)) return fail(VAH_E_NULL, "%s: bias / aux do not match the epilogue", fn);
+    if (epilogue != VAH_GEMM_EPI_NONE && epilogue != VAH_GEMM_EPI_BIAS) return fail(VAH_E_SHAPE, "%s: unknown epilogue", fn);
+    if ((epilogue == VAH_GEMM_EPI_BIAS) != (bias != nullptr)) return fail(VAH_E_NULL, "%s: bias does not match the epilogue", fn);
     if (workspace_bytes < 0 || (workspace_bytes > 0 && !workspace)) return fail(VAH_E_NULL, "%s: workspace", fn);
 
     State &S = state();
@@ -287,7 +275,7 @@ int vah_gemm_bf16(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, con
         if (s != HIPBLAS_STATUS_SUCCESS) return fail(VAH_E_UNSUPPORTED, "%s: hipblasLtCreate: %s", fn, status_name(s));
     }
     Call c{{trans_a ? 1 : 0, trans_b ? 1 : 0, d_is_f32 ? 1 : 0, epilogue, bias_is_f32 ? 1 : 0, M, N, K, lda, ldb, ldd},
-           A, B, bias, D, aux, ld_aux, workspace, (size_t)workspace_bytes, (hipStream_t)stream};
+           A, B, bias, D, workspace, (size_t)workspace_bytes, (hipStream_t)stream};
     Problem p;
     hipblasStatus_t s = make_problem(c, p);
     if (s != HIPBLAS_STATUS_SUCCESS) return fail(VAH_E_UNSUPPORTED, "%s: descriptor: %s", fn, status_name(s));

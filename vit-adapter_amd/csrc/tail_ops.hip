@@ -1,0 +1,406 @@
+// Output tail of the adapter backbone:  f = BatchNorm(a + b + upsample_s(x)).
+//
+// Reference: vit_adapter.py:106-127 (seg) / :101-120 (det)
+//     c1 = up(c2) + c1;  c1 = c1 + F.interpolate(x1, scale_factor=4, mode='bilinear');  f1 = norm1(c1)
+//     c2 = c2 + F.interpolate(x2, scale_factor=2, ...);  f2 = norm2(c2);  c3 = c3 + x3;  f3 = norm3(c3)
+// At 1024^2 the stride-4 map is 2 x 768 x 256 x 256 = 100 M elements; as separate ops (interpolate,
+// two adds, BN statistics, BN normalise) it is written or read ~10 times in fp32 (3.8 GB forward).
+// Here the sum is never materialised: the statistics pass and the normalise pass both recompute
+// a + b + bilinear(x) from the (bf16) operands, so the forward moves 2 reads of the operands plus
+// one fp32 write, and the backward likewise.  HBM-bound; no LDS except the adjoint of the upsample.
+//
+// Layout: NCHW planes.  a: bf16 or fp32 (N, C, H, W); b: optional, bf16 or fp32, same shape;
+// x: optional fp32 (N, C, H / s, W / s), s in {1, 2, 4, 8} (s = 1: plain add).  W % 4 == 0.
+// Bilinear taps follow torch's upsample_bilinear2d with align_corners = False and an explicit
+// scale factor:  src = (dst + 0.5) / s - 0.5, clamped at 0;  i1 = min(i0 + 1, n - 1).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+
+#include "../../include/vitadapter_hip.h"
+#include "common.h"
+
+namespace vah {
+namespace {
+
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+
+constexpr int kTilePx = 8192;           // hi-res pixels of one plane per workgroup
+constexpr int kTailParts = 512;         // partial rows of the channel sums (finalised below)
+
+struct Operands {
+    const void *a, *b;
+    const float *x;
+    int a_bf16, b_bf16, scale;
+    int C, H, W, Hl, Wl;
+    int rows_per_block, chunks;         // chunks of rows per plane
+};
+
+struct Tap {
+    int i0, i1;
+    float w1;
+};
+
+__device__ __forceinline__ Tap tap_of(int d, int n_lo, float inv_scale) {
+    float src = ((float)d + 0.5f) * inv_scale - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    Tap t;
+    t.i0 = min((int)src, n_lo - 1);
+    t.i1 = min(t.i0 + 1, n_lo - 1);
+    t.w1 = src - (float)t.i0;
+    return t;
+}
+
+__device__ __forceinline__ float4 load4(const void *p, int64_t idx, int is_bf16) {
+    if (is_bf16) {
+        const bf16x4 v = *reinterpret_cast<const bf16x4 *>(reinterpret_cast<const __bf16 *>(p) + idx);
+        return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+    }
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p) + idx);
+}
+
+__device__ __forceinline__ void store4(void *p, int64_t idx, int is_bf16, float4 v) {
+    if (is_bf16) {
+        bf16x4 o;
+        o[0] = (__bf16)v.x;
+        o[1] = (__bf16)v.y;
+        o[2] = (__bf16)v.z;
+        o[3] = (__bf16)v.w;
+        *reinterpret_cast<bf16x4 *>(reinterpret_cast<__bf16 *>(p) + idx) = o;
+    } else {
+        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(p) + idx) = v;
+    }
+}
+
+// t = a + b + up(x) for 4 consecutive pixels (row y, columns x4 .. x4 + 3) of plane `plane`.
+__device__ __forceinline__ float4 sum4(const Operands &o, int64_t plane, int y, int x4) {
+    const int64_t idx = (plane * o.H + y) * o.W + x4;
+    float4 t = load4(o.a, idx, o.a_bf16);
+    if (o.b) {
+        const float4 v = load4(o.b, idx, o.b_bf16);
+        t.x += v.x;
+        t.y += v.y;
+        t.z += v.z;
+        t.w += v.w;
+    }
+    if (o.x) {
+        const float *xp = o.x + plane * o.Hl * o.Wl;
+        if (o.scale == 1) {
+            const float4 v = *reinterpret_cast<const float4 *>(xp + (int64_t)y * o.Wl + x4);
+            t.x += v.x;
+            t.y += v.y;
+            t.z += v.z;
+            t.w += v.w;
+        } else {
+            const float inv = 1.f / (float)o.scale;
+            const Tap ty = tap_of(y, o.Hl, inv);
+            const float *r0 = xp + (int64_t)ty.i0 * o.Wl, *r1 = xp + (int64_t)ty.i1 * o.Wl;
+            float u[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const Tap tx = tap_of(x4 + k, o.Wl, inv);
+                const float top = r0[tx.i0] + tx.w1 * (r0[tx.i1] - r0[tx.i0]);
+                const float bot = r1[tx.i0] + tx.w1 * (r1[tx.i1] - r1[tx.i0]);
+                u[k] = top + ty.w1 * (bot - top);
+            }
+            t.x += u[0];
+            t.y += u[1];
+            t.z += u[2];
+            t.w += u[3];
+        }
+    }
+    return t;
+}
+
+__device__ __forceinline__ float block_sum(float v, float *s_red) {      // 256 threads
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) s_red[wv] = v;
+    __syncthreads();
+    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+}
+
+// part[(n * chunks + chunk)][2C]: (sum t | sum t^2) of the block's pixels, for its channel only; the
+// other columns of the row are left untouched, so the partial buffer is zero-filled by the host.
+__global__ __launch_bounds__(256) void tail_stats_kernel(Operands o, float *__restrict__ part) {
+    __shared__ float s_red[4];
+    const int64_t plane = blockIdx.x / o.chunks;
+    const int chunk = blockIdx.x % o.chunks;
+    const int c = (int)(plane % o.C);
+    const int64_t n = plane / o.C;
+    const int r0 = chunk * o.rows_per_block, r1 = min(o.H, r0 + o.rows_per_block);
+    const int wv4 = o.W >> 2;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < (r1 - r0) * wv4; i += 256) {
+        const int y = r0 + i / wv4, x4 = (i % wv4) * 4;
+        const float4 t = sum4(o, plane, y, x4);
+        s1 += (t.x + t.y) + (t.z + t.w);
+        s2 += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
+    }
+    s1 = block_sum(s1, s_red);
+    s2 = block_sum(s2, s_red);
+    if (threadIdx.x == 0) {
+        float *row = part + (n * o.chunks + chunk) * 2 * o.C;
+        row[c] = s1;
+        row[o.C + c] = s2;
+    }
+}
+
+__global__ __launch_bounds__(256) void tail_apply_kernel(Operands o, const float *__restrict__ mean,
+                                                         const float *__restrict__ rstd,
+                                                         const float *__restrict__ gamma,
+                                                         const float *__restrict__ beta, float *__restrict__ y) {
+    const int64_t plane = blockIdx.x / o.chunks;
+    const int chunk = blockIdx.x % o.chunks;
+    const int c = (int)(plane % o.C);
+    const int r0 = chunk * o.rows_per_block, r1 = min(o.H, r0 + o.rows_per_block);
+    const int wv4 = o.W >> 2;
+    const float sc = rstd[c] * (gamma ? gamma[c] : 1.f);
+    const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+    for (int i = threadIdx.x; i < (r1 - r0) * wv4; i += 256) {
+        const int yy = r0 + i / wv4, x4 = (i % wv4) * 4;
+        const float4 t = sum4(o, plane, yy, x4);
+        *reinterpret_cast<float4 *>(y + (plane * o.H + yy) * o.W + x4) =
+            make_float4(t.x * sc + sh, t.y * sc + sh, t.z * sc + sh, t.w * sc + sh);
+    }
+}
+
+// part row: (sum dy | sum dy * xhat) for the block's channel.
+__global__ __launch_bounds__(256) void tail_bwd_stats_kernel(Operands o, const float *__restrict__ mean,
+                                                             const float *__restrict__ rstd,
+                                                             const float *__restrict__ dy,
+                                                             float *__restrict__ part) {
+    __shared__ float s_red[4];
+    const int64_t plane = blockIdx.x / o.chunks;
+    const int chunk = blockIdx.x % o.chunks;
+    const int c = (int)(plane % o.C);
+    const int64_t n = plane / o.C;
+    const int r0 = chunk * o.rows_per_block, r1 = min(o.H, r0 + o.rows_per_block);
+    const int wv4 = o.W >> 2;
+    const float mu = mean[c], rs = rstd[c];
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < (r1 - r0) * wv4; i += 256) {
+        const int yy = r0 + i / wv4, x4 = (i % wv4) * 4;
+        const float4 t = sum4(o, plane, yy, x4);
+        const float4 g = *reinterpret_cast<const float4 *>(dy + (plane * o.H + yy) * o.W + x4);
+        s1 += (g.x + g.y) + (g.z + g.w);
+        s2 += (g.x * (t.x - mu) + g.y * (t.y - mu)) + (g.z * (t.z - mu) + g.w * (t.w - mu));
+    }
+    s1 = block_sum(s1, s_red);
+    s2 = block_sum(s2, s_red) * rs;
+    if (threadIdx.x == 0) {
+        float *row = part + (n * o.chunks + chunk) * 2 * o.C;
+        row[c] = s1;
+        row[o.C + c] = s2;
+    }
+}
+
+// dt = gamma * rstd * (dy - mdy - xhat * mdyx);  da = db = dt (in their own dtypes);
+// dx_lo += upsample^T(dt): the tile of dt is staged in LDS and every low-res pixel gathers its
+// (2s x 2s) footprint, separably (columns, then rows); rows shared with the neighbouring tile go
+// through fp32 atomics on the small low-res map.
+__global__ __launch_bounds__(256) void tail_bwd_apply_kernel(Operands o, const float *__restrict__ mean,
+                                                             const float *__restrict__ rstd,
+                                                             const float *__restrict__ gamma,
+                                                             const float *__restrict__ dy,
+                                                             const float *__restrict__ mdy,
+                                                             const float *__restrict__ mdyx, void *__restrict__ da,
+                                                             void *__restrict__ db, float *__restrict__ dxlo) {
+    extern __shared__ __attribute__((aligned(16))) float s_tile[];     // [rows][W] dt, then [rows][Wl] column sums
+    const int64_t plane = blockIdx.x / o.chunks;
+    const int chunk = blockIdx.x % o.chunks;
+    const int c = (int)(plane % o.C);
+    const int r0 = chunk * o.rows_per_block, r1 = min(o.H, r0 + o.rows_per_block);
+    const int rows = r1 - r0;
+    const int wv4 = o.W >> 2;
+    const float mu = mean[c], rs = rstd[c];
+    const float k = rs * (gamma ? gamma[c] : 1.f), m1 = mdy[c], m2 = mdyx[c];
+    const bool want_lo = dxlo != nullptr && o.x != nullptr;
+    for (int i = threadIdx.x; i < rows * wv4; i += 256) {
+        const int yy = r0 + i / wv4, x4 = (i % wv4) * 4;
+        const int64_t idx = (plane * o.H + yy) * o.W + x4;
+        const float4 t = sum4(o, plane, yy, x4);
+        const float4 g = *reinterpret_cast<const float4 *>(dy + idx);
+        const float4 d = make_float4(k * (g.x - m1 - (t.x - mu) * rs * m2), k * (g.y - m1 - (t.y - mu) * rs * m2),
+                                     k * (g.z - m1 - (t.z - mu) * rs * m2), k * (g.w - m1 - (t.w - mu) * rs * m2));
+        if (da) store4(da, idx, o.a_bf16, d);
+        if (db) store4(db, idx, o.b_bf16, d);
+        if (want_lo) {
+            if (o.scale == 1) *reinterpret_cast<float4 *>(dxlo + idx) = d;      // same grid: plain store
+            else *reinterpret_cast<float4 *>(s_tile + (yy - r0) * o.W + x4) = d;
+        }
+    }
+    if (!want_lo || o.scale == 1) return;
+    __syncthreads();
+    const float inv = 1.f / (float)o.scale;
+    const int s = o.scale;
+    float *s_col = s_tile + rows * o.W;                                  // [rows][Wl]
+    for (int i = threadIdx.x; i < rows * o.Wl; i += 256) {
+        const int ry = i / o.Wl, j = i % o.Wl;
+        const float *row = s_tile + ry * o.W;
+        float acc = 0.f;
+        const int xa = max(0, s * (j - 1)), xb = min(o.W - 1, s * (j + 2) - 1);
+        for (int x = xa; x <= xb; ++x) {
+            const Tap t = tap_of(x, o.Wl, inv);
+            const float w = (t.i0 == j ? 1.f - t.w1 : 0.f) + (t.i1 == j ? t.w1 : 0.f);
+            acc += w * row[x];
+        }
+        s_col[i] = acc;
+    }
+    __syncthreads();
+    const int i_lo = tap_of(r0, o.Hl, inv).i0, i_hi = tap_of(r1 - 1, o.Hl, inv).i1;
+    float *out = dxlo + plane * o.Hl * o.Wl;
+    for (int i = threadIdx.x; i < (i_hi - i_lo + 1) * o.Wl; i += 256) {
+        const int li = i_lo + i / o.Wl, j = i % o.Wl;
+        const int ya = max(r0, s * (li - 1)), yb = min(r1 - 1, s * (li + 2) - 1);
+        float acc = 0.f;
+        for (int y = ya; y <= yb; ++y) {
+            const Tap t = tap_of(y, o.Hl, inv);
+            const float w = (t.i0 == li ? 1.f - t.w1 : 0.f) + (t.i1 == li ? t.w1 : 0.f);
+            acc += w * s_col[(y - r0) * o.Wl + j];
+        }
+        // rows whose footprint lies wholly inside this tile are owned by it; the others are shared
+        const bool owned = s * (li - 1) >= r0 && s * (li + 2) - 1 <= r1 - 1;
+        if (owned || (li == 0 && r0 == 0 && s * (li + 2) - 1 <= r1 - 1) ||
+            (li == o.Hl - 1 && r1 == o.H && s * (li - 1) >= r0))
+            out[(int64_t)li * o.Wl + j] += acc;                         // no other workgroup touches this row
+        else
+            atomicAdd(out + (int64_t)li * o.Wl + j, acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void tail_finalize(const float *__restrict__ part, int nparts, int K,
+                                                     float *__restrict__ out) {
+    __shared__ float s_acc[8][32];
+    const int col = threadIdx.x & 31, pl = threadIdx.x >> 5;
+    const int k = blockIdx.x * 32 + col;
+    float acc = 0.f;
+    if (k < K)
+        for (int p = pl; p < nparts; p += 8) acc += part[(int64_t)p * K + k];
+    s_acc[pl][col] = acc;
+    __syncthreads();
+    if (pl == 0 && k < K) {
+        float t = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += s_acc[u][col];
+        out[k] = t;
+    }
+}
+
+int fill_operands(const char *fn, Operands &o, const void *a, int a_bf16, const void *b, int b_bf16, const float *x,
+                  int scale, int64_t N, int64_t C, int64_t H, int64_t W) {
+    if (N < 1 || C < 1 || H < 1 || W < 4 || W % 4 || W > kTilePx) return fail(VAH_E_SHAPE, "%s: bad shape", fn);
+    if (scale != 1 && scale != 2 && scale != 4 && scale != 8) return fail(VAH_E_SHAPE, "%s: scale must be 1, 2, 4 or 8", fn);
+    if (x && (H % scale || W % scale || (W / scale) % 4)) return fail(VAH_E_SHAPE, "%s: H, W not multiples of the scale", fn);
+    if (N * C * H * W >= ((int64_t)1 << 40)) return fail(VAH_E_SHAPE, "%s: too large", fn);
+    if (!a) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if (((uintptr_t)a | (uintptr_t)b) % 8 || (uintptr_t)x % 16 || (!a_bf16 && (uintptr_t)a % 16) || (b && !b_bf16 && (uintptr_t)b % 16))
+        return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    o.a = a;
+    o.b = b;
+    o.x = x;
+    o.a_bf16 = a_bf16;
+    o.b_bf16 = b_bf16;
+    o.scale = scale;
+    o.C = (int)C;
+    o.H = (int)H;
+    o.W = (int)W;
+    o.Hl = (int)(H / scale);
+    o.Wl = (int)(W / scale);
+    int rpb = std::max<int>(1, kTilePx / (int)W);
+    rpb = std::max(scale * 2, rpb / (scale * 2) * (scale * 2));        // multiple of 2s: tiles end between footprints
+    rpb = std::min<int>(rpb, (int)H);
+    o.rows_per_block = rpb;
+    o.chunks = (int)((H + rpb - 1) / rpb);
+    if (N * o.chunks > kTailParts) {                                     // keep the partial rows bounded
+        o.chunks = std::max<int>(1, kTailParts / (int)N);
+        o.rows_per_block = (int)((H + o.chunks - 1) / o.chunks);
+        o.rows_per_block = (o.rows_per_block + 2 * scale - 1) / (2 * scale) * (2 * scale);
+        o.chunks = (int)((H + o.rows_per_block - 1) / o.rows_per_block);
+    }
+    return VAH_OK;
+}
+
+}  // namespace
+}  // namespace vah
+
+extern "C" {
+
+int64_t vah_bn_tail_ws_floats(int64_t C) { return (int64_t)vah::kTailParts * 2 * C; }
+
+int vah_bn_tail_stats(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale, int64_t N,
+                      int64_t C, int64_t H, int64_t W, float *sums, float *ws, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_bn_tail_stats";
+    Operands o;
+    if (int rc = fill_operands(fn, o, a, a_bf16, b, b_bf16, x, scale, N, C, H, W)) return rc;
+    if (!sums || !ws) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    hipStream_t st = (hipStream_t)stream;
+    const int nparts = (int)N * o.chunks;
+    LaunchScope scope("bn_tail_stats", N * C * H * W * ((a_bf16 ? 2 : 4) + (b ? (b_bf16 ? 2 : 4) : 0)), st);
+    hipLaunchKernelGGL(tail_stats_kernel, dim3((unsigned)(N * C * o.chunks)), dim3(256), 0, st, o, ws);
+    hipLaunchKernelGGL(tail_finalize, dim3((unsigned)((2 * C + 31) / 32)), dim3(256), 0, st, ws, nparts, (int)(2 * C), sums);
+    return check_launch(fn);
+}
+
+int vah_bn_tail_apply(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale, int64_t N,
+                      int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd, const float *gamma,
+                      const float *beta, float *y, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_bn_tail_apply";
+    Operands o;
+    if (int rc = fill_operands(fn, o, a, a_bf16, b, b_bf16, x, scale, N, C, H, W)) return rc;
+    if (!mean || !rstd || !y) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if ((uintptr_t)y % 16) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    hipStream_t st = (hipStream_t)stream;
+    LaunchScope scope("bn_tail_apply", N * C * H * W * ((a_bf16 ? 2 : 4) + (b ? (b_bf16 ? 2 : 4) : 0) + 4), st);
+    hipLaunchKernelGGL(tail_apply_kernel, dim3((unsigned)(N * C * o.chunks)), dim3(256), 0, st, o, mean, rstd, gamma, beta, y);
+    return check_launch(fn);
+}
+
+int vah_bn_tail_bwd_stats(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale, int64_t N,
+                          int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd, const float *dy,
+                          float *sums, float *ws, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_bn_tail_bwd_stats";
+    Operands o;
+    if (int rc = fill_operands(fn, o, a, a_bf16, b, b_bf16, x, scale, N, C, H, W)) return rc;
+    if (!mean || !rstd || !dy || !sums || !ws) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if ((uintptr_t)dy % 16) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    hipStream_t st = (hipStream_t)stream;
+    const int nparts = (int)N * o.chunks;
+    LaunchScope scope("bn_tail_bwd_stats", N * C * H * W * ((a_bf16 ? 2 : 4) + (b ? (b_bf16 ? 2 : 4) : 0) + 4), st);
+    hipLaunchKernelGGL(tail_bwd_stats_kernel, dim3((unsigned)(N * C * o.chunks)), dim3(256), 0, st, o, mean, rstd, dy, ws);
+    hipLaunchKernelGGL(tail_finalize, dim3((unsigned)((2 * C + 31) / 32)), dim3(256), 0, st, ws, nparts, (int)(2 * C), sums);
+    return check_launch(fn);
+}
+
+int vah_bn_tail_bwd_apply(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale, int64_t N,
+                          int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd, const float *gamma,
+                          const float *dy, const float *mdy, const float *mdyx, void *da, void *db, float *dxlo,
+                          void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_bn_tail_bwd_apply";
+    Operands o;
+    if (int rc = fill_operands(fn, o, a, a_bf16, b, b_bf16, x, scale, N, C, H, W)) return rc;
+    if (!mean || !rstd || !dy || !mdy || !mdyx) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if (((uintptr_t)dy | (uintptr_t)dxlo) % 16 || ((uintptr_t)da | (uintptr_t)db) % 8) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    hipStream_t st = (hipStream_t)stream;
+    size_t smem = 0;
+    if (dxlo && x && scale > 1) smem = (size_t)o.rows_per_block * (o.W + o.Wl) * sizeof(float);
+    if (smem > 150 * 1024) return fail(VAH_E_SHAPE, "%s: tile does not fit LDS", fn);
+    LaunchScope scope("bn_tail_bwd_apply", N * C * H * W * (2 * ((a_bf16 ? 2 : 4) + (b ? (b_bf16 ? 2 : 4) : 0)) + 4), st);
+    if (smem > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)tail_bwd_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    hipLaunchKernelGGL(tail_bwd_apply_kernel, dim3((unsigned)(N * C * o.chunks)), dim3(256), smem, st, o, mean, rstd, gamma,
+                       dy, mdy, mdyx, da, db, dxlo);
+    return check_launch(fn);
+}
+
+}  // extern "C"

@@ -139,18 +139,18 @@ class ViTAdapter(TIMMVisionTransformer):
         c2 = c[:, :n2].transpose(1, 2).reshape(bs, dim, H * 2, W * 2).contiguous()
         c3 = c[:, n2:n2 + n3].transpose(1, 2).reshape(bs, dim, H, W).contiguous()
         c4 = c[:, n2 + n3:].transpose(1, 2).reshape(bs, dim, H // 2, W // 2).contiguous()
-        c1 = self.up(c2) + c1
-
         if self.add_vit_feature:
             if self.flavour == 'seg':
                 x1, x2, x3, x4 = stage_maps
             else:
                 x1 = x2 = x3 = x4 = x.transpose(1, 2).reshape(bs, dim, H, W).contiguous()
-            c1 = c1 + F.interpolate(x1, scale_factor=4, mode='bilinear', align_corners=False)
-            c2 = c2 + F.interpolate(x2, scale_factor=2, mode='bilinear', align_corners=False)
-            c3 = c3 + x3
+            # f1 = norm1(up(c2) + c1 + interp(x1, 4)), f2 = norm2(c2 + interp(x2, 2)), f3 = norm3(c3 + x3):
+            # sum, upsampling and batch norm in one pair of passes (csrc/tail_ops.hip); off the bf16
+            # GPU path fused.bn_tail evaluates exactly the reference expression
             c4 = c4 + F.interpolate(x4, scale_factor=0.5, mode='bilinear', align_corners=False)
-
+            return [fused.bn_tail(self.norm1, self.up(c2), c1, x1, 4), fused.bn_tail(self.norm2, c2, None, x2, 2),
+                    fused.bn_tail(self.norm3, c3, None, x3, 1), self.norm4(c4)]
+        c1 = self.up(c2) + c1
         return [self.norm1(c1), self.norm2(c2), self.norm3(c3), self.norm4(c4)]
 
 

@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 import _vah
 
-ENABLED = {'layer_norm': True, 'residual': True, 'dwconv': True, 'linear': True}
+ENABLED = {'layer_norm': True, 'residual': True, 'dwconv': True, 'linear': True, 'bn_tail': True}
 
 
 def _stream(t):
@@ -181,8 +181,7 @@ def _configure_gemm():
 _configure_gemm()
 
 
-def gemm_bf16(a, b, trans_a=False, trans_b=False, out_dtype=torch.bfloat16, bias=None,
-              epilogue=None, aux=None):
+def gemm_bf16(a, b, trans_a=False, trans_b=False, out_dtype=torch.bfloat16, bias=None):
     """op(a) @ op(b) for contiguous 2-D bf16 matrices on the tuned hipBLASLt dispatcher
     (csrc/gemm.hip); fp32 accumulation, bf16 or fp32 result."""
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
@@ -194,16 +193,13 @@ def gemm_bf16(a, b, trans_a=False, trans_b=False, out_dtype=torch.bfloat16, bias
     if K == 0:
         return d.zero_()
     ws = torch.empty(_GEMM_WS_BYTES, dtype=torch.uint8, device=a.device)
-    if epilogue is None:
-        epilogue = _vah.GEMM_EPI_BIAS if bias is not None else _vah.GEMM_EPI_NONE
+    epilogue = _vah.GEMM_EPI_BIAS if bias is not None else _vah.GEMM_EPI_NONE
     with torch.cuda.device(a.device):
         _vah.check(_vah.lib.vah_gemm_bf16(
             int(trans_a), int(trans_b), M, N, K, a.data_ptr(), a.shape[1], b.data_ptr(), b.shape[1],
             d.data_ptr(), N, int(out_dtype == torch.float32), epilogue,
             bias.data_ptr() if bias is not None else None,
-            int(bias is not None and bias.dtype == torch.float32),
-            aux.data_ptr() if aux is not None else None, aux.shape[1] if aux is not None else 0,
-            ws.data_ptr(), _GEMM_WS_BYTES, _stream(a)), 'gemm_bf16')
+            int(bias is not None and bias.dtype == torch.float32), ws.data_ptr(), _GEMM_WS_BYTES, _stream(a)), 'gemm_bf16')
     return d
 
 
@@ -360,3 +356,124 @@ def dwconv_tokens(conv, x, H, W):
             and conv.weight.shape == (C, 1, 3, 3)):
         return _DWConvTokens.apply(x, conv.weight, conv.bias, H, W)
     return None
+
+
+# ---------------------------------------------------------------------------------------
+# output tail: BatchNorm(a + b + bilinear_upsample(x))
+# ---------------------------------------------------------------------------------------
+def _sync_group(norm):
+    """Process group whose ranks share the statistics of a SyncBatchNorm in training (None: local)."""
+    import torch.distributed as dist
+    if not isinstance(norm, torch.nn.SyncBatchNorm) or not dist.is_available() or not dist.is_initialized():
+        return None
+    group = norm.process_group if norm.process_group is not None else dist.group.WORLD
+    return group if dist.get_world_size(group) > 1 else None
+
+
+class _BNTail(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, x, weight, bias, norm, scale):
+        N, C, H, W = a.shape
+        a = a.contiguous()
+        b = b.contiguous() if b is not None else None
+        x = x.contiguous().float() if x is not None else None
+        dev, st = a.device, _stream(a)
+        ops = (a.data_ptr(), int(a.dtype == torch.bfloat16), b.data_ptr() if b is not None else None,
+               int(b is not None and b.dtype == torch.bfloat16), x.data_ptr() if x is not None else None,
+               scale, N, C, H, W)
+        training = norm.training or norm.running_mean is None
+        group = _sync_group(norm) if training else None
+        with torch.cuda.device(dev):
+            if training:
+                sums = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
+                ws = torch.empty(_vah.lib.vah_bn_tail_ws_floats(C), dtype=torch.float32, device=dev)
+                _vah.check(_vah.lib.vah_bn_tail_stats(*ops, sums.data_ptr(), ws.data_ptr(), st), 'bn_tail_stats')
+                sums[2 * C] = float(N * H * W)
+                if group is not None:
+                    import torch.distributed as dist
+                    dist.all_reduce(sums, group=group)
+                count = sums[2 * C]
+                mean = sums[:C] / count
+                var = (sums[C:2 * C] / count - mean * mean).clamp_(min=0.)
+                if norm.running_mean is not None:
+                    with torch.no_grad():
+                        m = norm.momentum
+                        norm.num_batches_tracked += 1
+                        if m is None:
+                            m = 1.0 / float(norm.num_batches_tracked)
+                        norm.running_mean.mul_(1 - m).add_(mean, alpha=m)
+                        norm.running_var.mul_(1 - m).add_(var * (count / (count - 1)), alpha=m)
+            else:
+                count = None
+                mean, var = norm.running_mean.float(), norm.running_var.float()
+            rstd = torch.rsqrt(var + norm.eps)
+            mean = mean.contiguous()
+            w = weight.detach().float().contiguous() if weight is not None else None
+            bb = bias.detach().float().contiguous() if bias is not None else None
+            y = torch.empty((N, C, H, W), dtype=torch.float32, device=dev)
+            _vah.check(_vah.lib.vah_bn_tail_apply(
+                *ops, mean.data_ptr(), rstd.data_ptr(), w.data_ptr() if w is not None else None,
+                bb.data_ptr() if bb is not None else None, y.data_ptr(), st), 'bn_tail_apply')
+        ctx.save_for_backward(a, b, x, mean, rstd, w, count)
+        ctx.meta = (scale, training, group, b.dtype if b is not None else None, weight is not None, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b, x, mean, rstd, w, count = ctx.saved_tensors
+        scale, training, group, _, has_w, has_b = ctx.meta
+        N, C, H, W = a.shape
+        dy = dy.contiguous().float()
+        dev, st = a.device, _stream(a)
+        ops = (a.data_ptr(), int(a.dtype == torch.bfloat16), b.data_ptr() if b is not None else None,
+               int(b is not None and b.dtype == torch.bfloat16), x.data_ptr() if x is not None else None,
+               scale, N, C, H, W)
+        with torch.cuda.device(dev):
+            sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
+            ws = torch.empty(_vah.lib.vah_bn_tail_ws_floats(C), dtype=torch.float32, device=dev)
+            _vah.check(_vah.lib.vah_bn_tail_bwd_stats(*ops, mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(),
+                                                      sums.data_ptr(), ws.data_ptr(), st), 'bn_tail_bwd_stats')
+            dweight = sums[C:].clone() if has_w else None
+            dbias = sums[:C].clone() if has_b else None
+            if training:
+                if group is not None:
+                    import torch.distributed as dist
+                    dist.all_reduce(sums, group=group)
+                means = sums / count
+            else:
+                means = torch.zeros_like(sums)          # running statistics are constants
+            need_a, need_b, need_x = ctx.needs_input_grad[:3]
+            da = torch.empty_like(a) if need_a else None
+            db = torch.empty_like(b) if (b is not None and need_b) else None
+            dx = None
+            if x is not None and need_x:
+                dx = torch.zeros_like(x) if scale > 1 else torch.empty_like(x)
+            if da is not None or db is not None or dx is not None:
+                _vah.check(_vah.lib.vah_bn_tail_bwd_apply(
+                    *ops, mean.data_ptr(), rstd.data_ptr(), w.data_ptr() if w is not None else None,
+                    dy.data_ptr(), means[:C].data_ptr(), means[C:].data_ptr(),
+                    da.data_ptr() if da is not None else None, db.data_ptr() if db is not None else None,
+                    dx.data_ptr() if dx is not None else None, st), 'bn_tail_bwd_apply')
+        return da, db, dx, dweight, dbias, None, None
+
+
+def bn_tail(norm, a, b=None, x=None, scale=1):
+    """``norm(a + b + F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=False))``
+    for a (Sync)BatchNorm2d ``norm`` - the output tail of the backbone (ref vit_adapter.py:106-127);
+    ``b`` / ``x`` optional, ``scale == 1`` adds ``x`` as it is."""
+    bn = isinstance(norm, torch.nn.modules.batchnorm._BatchNorm)
+    if (ENABLED['bn_tail'] and bn and a.is_cuda and _bf16_autocast() and a.dim() == 4 and x is not None
+            and a.dtype in (torch.bfloat16, torch.float32) and (b is None or (b.shape == a.shape and b.dtype in
+                                                                               (torch.bfloat16, torch.float32)))
+            and scale in (1, 2, 4, 8) and a.shape[3] % (4 * scale) == 0 and a.shape[2] % scale == 0
+            and a.shape[3] <= 8192 and tuple(x.shape) == (a.shape[0], a.shape[1], a.shape[2] // scale, a.shape[3] // scale)
+            and x.dtype in (torch.bfloat16, torch.float32) and a.numel() > 0
+            and (not norm.training or a.shape[0] * a.shape[2] * a.shape[3] > 1)
+            and (norm.training or norm.running_mean is not None)
+            and (norm.weight is None or norm.weight.dtype == torch.float32)):
+        return _BNTail.apply(a, b, x, norm.weight, norm.bias, norm, scale)
+    t = a if b is None else a + b
+    if x is not None:
+        t = t + (x if scale == 1 else F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=False))
+    return norm(t)
+
