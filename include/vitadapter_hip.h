@@ -275,14 +275,19 @@ int vah_bn_tail_bwd_apply(const void *a, int a_bf16, const void *b, int b_bf16, 
  * The library times the hipBLASLt candidates of every new problem once on the caller's stream
  * (vah_gemm_set_tuning: mode 0 = first heuristic answer, 1 = time `candidates` heuristic answers
  * [default, 32], 2 = time every algorithm of the library) and caches the winner; the cache can be
- * dumped / loaded as text ("ta tb d32 epi bias32 M N K lda ldb ldd algo_index us" per line).
- * workspace: caller-provided scratch (32 MiB is ample), private to the stream. */
+ * dumped / loaded as text ("ta tb d32 epi bias32 M N K lda ldb ldd algo_index split us" per line).
+ * Long reductions into few output tiles (K >= 4096, no bias) may run as `split` strided-batch
+ * slices of K with fp32 partial products in the workspace and one reduction pass; the split is
+ * part of the timed choice and bounded by the workspace.
+ * workspace: caller-provided scratch private to the stream; 32 MiB for the library plus, to allow
+ * split-K, split * M * N * 4 bytes. */
 #define VAH_GEMM_EPI_NONE 0
 #define VAH_GEMM_EPI_BIAS 1
 int vah_gemm_set_tuning(int mode, int candidates);
 int vah_gemm_bf16(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
                   const void *B, int64_t ldb, void *D, int64_t ldd, int d_is_f32, int epilogue,
                   const void *bias, int bias_is_f32, void *workspace, int64_t workspace_bytes, void *stream);
+int64_t vah_gemm_library_version(void);                /* hipBLASLt build the algorithm indices belong to */
 int64_t vah_gemm_table_dump(char *buf, int64_t cap);   /* returns the size needed (incl. NUL) */
 int vah_gemm_table_load(const char *text);             /* returns the number of entries, < 0 on error */
 /* y = x + s[b] * gamma[c] * z   (x, y fp32 (batch, rows_per_batch, C); z bf16; gamma (C) or NULL;

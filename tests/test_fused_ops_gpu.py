@@ -249,7 +249,9 @@ def test_gemm_table_roundtrip():
     text = _vah.gemm_table_dump()
     line = [ln for ln in text.splitlines() if ln.startswith('0 0 0 0 0 64 256 128 ')]
     assert len(line) == 1, text
-    assert _vah.gemm_table_load(text) == len(text.splitlines())
+    assert text.startswith('#hipblaslt ')
+    assert _vah.gemm_table_load(text) == len(text.splitlines()) - 1
+    assert _vah.gemm_table_load('#hipblaslt 1\n' + text.split('\n', 1)[1]) == 0      # other build: ignored
     assert torch.equal(fused.gemm_bf16(a, b), d)   # entries are re-resolved from their index
     with pytest.raises(RuntimeError):
         _vah.gemm_table_load('not a table line')

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -80,6 +80,8 @@ lib.vah_gemm_bf16.argtypes = [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, 
 lib.vah_gemm_table_dump.argtypes = [ctypes.c_char_p, _i64]
 lib.vah_gemm_table_dump.restype = _i64
 lib.vah_gemm_table_load.argtypes = [ctypes.c_char_p]
+lib.vah_gemm_library_version.argtypes = []
+lib.vah_gemm_library_version.restype = _i64
 _tail_in = [_p, _int, _p, _int, _p, _int, _i64, _i64, _i64, _i64]
 lib.vah_bn_tail_ws_floats.argtypes = [_i64]
 lib.vah_bn_tail_ws_floats.restype = _i64
@@ -114,7 +116,7 @@ EXPORTS = (
     'vah_attn_win_fwd_bf16', 'vah_attn_win_bwd_bf16',
     'vah_reduce_ws_floats', 'vah_layernorm_fwd_f32_bf16', 'vah_layernorm_bwd_f32_bf16', 'vah_scale_residual_fwd',
     'vah_scale_residual_bwd', 'vah_dwconv3x3_tokens_bf16', 'vah_dwconv3x3_tokens_wgrad_bf16', 'vah_colsum_bf16',
-    'vah_gemm_set_tuning', 'vah_gemm_bf16', 'vah_gemm_table_dump', 'vah_gemm_table_load',
+    'vah_gemm_set_tuning', 'vah_gemm_bf16', 'vah_gemm_table_dump', 'vah_gemm_table_load', 'vah_gemm_library_version',
     'vah_bn_tail_ws_floats', 'vah_bn_tail_stats', 'vah_bn_tail_apply', 'vah_bn_tail_bwd_stats', 'vah_bn_tail_bwd_apply',
 )
 
@@ -146,14 +148,20 @@ GEMM_EPI_NONE, GEMM_EPI_BIAS = 0, 1
 
 
 def gemm_table_dump():
-    """The GEMM algorithm cache as text (one problem per line, see include/vitadapter_hip.h)."""
+    """The GEMM algorithm cache as text: a '#hipblaslt <version>' line, then one problem per line
+    (see include/vitadapter_hip.h)."""
     n = lib.vah_gemm_table_dump(None, 0)
     buf = ctypes.create_string_buffer(int(n))
     lib.vah_gemm_table_dump(buf, n)
-    return buf.value.decode()
+    return '#hipblaslt %d\n' % lib.vah_gemm_library_version() + buf.value.decode()
 
 
 def gemm_table_load(text):
+    """Load a dumped table; a table of another hipBLASLt build is ignored (returns 0): its
+    algorithm indices mean nothing here and every problem is simply timed again."""
+    first = text.split('\n', 1)[0].split()
+    if len(first) == 2 and first[0] == '#hipblaslt' and int(first[1]) != lib.vah_gemm_library_version():
+        return 0
     n = lib.vah_gemm_table_load(text.encode())
     if n < 0:
         check(n, 'gemm_table_load')

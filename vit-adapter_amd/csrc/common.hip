@@ -82,7 +82,7 @@ LaunchScope::~LaunchScope() {
 
 extern "C" {
 
-int vah_abi_version(void) { return 13; }
+int vah_abi_version(void) { return 14; }
 
 const char *vah_last_error(void) { return vah::g_err; }
 

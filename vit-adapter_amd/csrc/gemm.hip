@@ -10,6 +10,10 @@
 //     loaded as text so a tuned table can be shipped.
 //   * the weight gradient is written in fp32 straight from the accumulators (no bf16 rounding of
 //     the gradient and no cast kernel per parameter).
+//   * split-K.  The adapter's weight gradients reduce over 43008 token rows into outputs of at most
+//     768 x 768: 18..72 output tiles for 256 CUs.  hipBLASLt runs them at 0.2 PFLOP/s; the same
+//     library run as a strided batch over S slices of the rows (S x more tiles) plus one reduction
+//     pass over the S fp32 partial products is 2-3x faster.  S is part of the timed choice.
 // Row-major in, row-major out; hipBLASLt is column-major, so D^T = op(B)^T op(A)^T is what is run.
 #include <hip/hip_runtime.h>
 #include <hipblaslt/hipblaslt-ext.hpp>
@@ -45,6 +49,7 @@ struct Choice {
     hipblasLtMatmulAlgo_t algo;
     size_t workspace = 0;
     int index = -1;          // hipblaslt_ext algorithm index (stable within one library build)
+    int split = 1;           // slices of the reduction dimension (1: hipBLASLt writes D itself)
     float us = 0.f;          // measured time of the winner (0: not measured)
     bool resolved = false;   // algo valid (an entry loaded from text is resolved on first use)
 };
@@ -95,8 +100,16 @@ struct Call {
     hipStream_t st;
 };
 
-hipblasStatus_t make_problem(const Call &c, Problem &p) {
-    const Key &k = c.k;
+// split > 1: a strided batch over `split` equal slices of the K rows; the fp32 partial products
+// (split, M, N) land in the workspace and reduce_splits() sums them into D.
+hipblasStatus_t make_problem(const Call &c, Problem &p, int split) {
+    const Key &k0 = c.k;
+    Key k = k0;
+    k.K = k0.K / split;
+    if (split > 1) {
+        k.d32 = 1;
+        k.ldd = k0.N;
+    }
     hipblasStatus_t s = hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F);
     if (s != HIPBLAS_STATUS_SUCCESS) return s;
     // column-major view: first operand = our B, second = our A
@@ -111,6 +124,17 @@ hipblasStatus_t make_problem(const Call &c, Problem &p) {
     if (s != HIPBLAS_STATUS_SUCCESS) return s;
     s = hipblasLtMatrixLayoutCreate(&p.ld, k.d32 ? HIP_R_32F : HIP_R_16BF, k.N, k.M, k.ldd);
     if (s != HIPBLAS_STATUS_SUCCESS) return s;
+    if (split > 1) {
+        const int32_t batch = split;
+        // a slice of the K rows: K/split rows further down (operand stored K-major) or K/split columns along
+        const int64_t sa = k.ta ? k.K * k.lda : k.K, sb = k.tb ? k.K : k.K * k.ldb, sd = k.M * k.N;
+        hipblasLtMatrixLayoutSetAttribute(p.la, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &batch, sizeof(batch));
+        hipblasLtMatrixLayoutSetAttribute(p.lb, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &batch, sizeof(batch));
+        hipblasLtMatrixLayoutSetAttribute(p.ld, HIPBLASLT_MATRIX_LAYOUT_BATCH_COUNT, &batch, sizeof(batch));
+        hipblasLtMatrixLayoutSetAttribute(p.la, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &sb, sizeof(sb));
+        hipblasLtMatrixLayoutSetAttribute(p.lb, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &sa, sizeof(sa));
+        hipblasLtMatrixLayoutSetAttribute(p.ld, HIPBLASLT_MATRIX_LAYOUT_STRIDED_BATCH_OFFSET, &sd, sizeof(sd));
+    }
     uint32_t epi = HIPBLASLT_EPILOGUE_DEFAULT;
     switch (k.epi) {
     case VAH_GEMM_EPI_NONE: break;
@@ -126,43 +150,86 @@ hipblasStatus_t make_problem(const Call &c, Problem &p) {
     return HIPBLAS_STATUS_SUCCESS;
 }
 
-hipblasStatus_t run(State &S, const Call &c, Problem &p, const hipblasLtMatmulAlgo_t &algo, size_t ws_need) {
-    if (ws_need > c.ws_bytes) return HIPBLAS_STATUS_ALLOC_FAILED;
+size_t partial_bytes(const Key &k, int split) {
+    return split > 1 ? ((size_t)split * k.M * k.N * sizeof(float) + 255) / 256 * 256 : 0;
+}
+
+template <typename OT>
+__global__ __launch_bounds__(256) void reduce_splits(const float *__restrict__ part, int split, int64_t MN, int N,
+                                                     int64_t ldd, OT *__restrict__ out) {
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < MN; i += (int64_t)gridDim.x * 1024) {
+        float4 acc = *reinterpret_cast<const float4 *>(part + i);
+        for (int s = 1; s < split; ++s) {
+            const float4 v = *reinterpret_cast<const float4 *>(part + s * MN + i);
+            acc.x += v.x;
+            acc.y += v.y;
+            acc.z += v.z;
+            acc.w += v.w;
+        }
+        const int64_t row = i / N;
+        OT *o = out + row * ldd + (i - row * N);
+        o[0] = (OT)acc.x;
+        o[1] = (OT)acc.y;
+        o[2] = (OT)acc.z;
+        o[3] = (OT)acc.w;
+    }
+}
+
+hipblasStatus_t run(State &S, const Call &c, Problem &p, const hipblasLtMatmulAlgo_t &algo, size_t ws_need, int split) {
+    const size_t pb = partial_bytes(c.k, split);
+    if (pb + ws_need > c.ws_bytes) return HIPBLAS_STATUS_ALLOC_FAILED;
     const float alpha = 1.f, beta = 0.f;
+    void *d = split > 1 ? c.ws : c.D;
     // operands swapped: see the header comment
-    return hipblasLtMatmul(S.handle, p.desc, &alpha, c.B, p.la, c.A, p.lb, &beta, c.D, p.ld, c.D, p.ld, &algo,
-                           c.ws, c.ws_bytes, c.st);
+    const hipblasStatus_t s = hipblasLtMatmul(S.handle, p.desc, &alpha, c.B, p.la, c.A, p.lb, &beta, d, p.ld, d, p.ld, &algo,
+                                              (char *)c.ws + pb, c.ws_bytes - pb, c.st);
+    if (s != HIPBLAS_STATUS_SUCCESS || split == 1) return s;
+    const int64_t MN = c.k.M * c.k.N;
+    const unsigned blocks = (unsigned)std::min<int64_t>(2048, (MN / 4 + 255) / 256);
+    if (c.k.d32)
+        hipLaunchKernelGGL(reduce_splits<float>, dim3(blocks), dim3(256), 0, c.st, (const float *)c.ws, split, MN, (int)c.k.N,
+                           c.k.ldd, (float *)c.D);
+    else
+        hipLaunchKernelGGL(reduce_splits<__bf16>, dim3(blocks), dim3(256), 0, c.st, (const float *)c.ws, split, MN,
+                           (int)c.k.N, c.k.ldd, (__bf16 *)c.D);
+    return HIPBLAS_STATUS_SUCCESS;
 }
 
 // Time one candidate on the caller's stream (the output is simply overwritten).
-float time_algo(State &S, const Call &c, Problem &p, const hipblasLtMatmulAlgo_t &algo, size_t ws_need,
+float time_algo(State &S, const Call &c, Problem &p, const hipblasLtMatmulAlgo_t &algo, size_t ws_need, int split,
                 hipEvent_t e0, hipEvent_t e1, int reps) {
-    if (run(S, c, p, algo, ws_need) != HIPBLAS_STATUS_SUCCESS) return -1.f;      // warm-up + validity
+    if (run(S, c, p, algo, ws_need, split) != HIPBLAS_STATUS_SUCCESS) return -1.f;      // warm-up + validity
     if (hipEventRecord(e0, c.st) != hipSuccess) return -1.f;
     for (int i = 0; i < reps; ++i)
-        if (run(S, c, p, algo, ws_need) != HIPBLAS_STATUS_SUCCESS) return -1.f;
+        if (run(S, c, p, algo, ws_need, split) != HIPBLAS_STATUS_SUCCESS) return -1.f;
     if (hipEventRecord(e1, c.st) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return -1.f;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.f;
     return ms * 1000.f / reps;
 }
 
-hipblasStatus_t choose(State &S, const Call &c, Problem &p, Choice &out) {
+// Best algorithm for one value of `split` (timed unless there is a single candidate and nothing to
+// compare it with).
+hipblasStatus_t choose_for_split(State &S, const Call &c, Problem &p, int split, bool must_time, Choice &out) {
+    const size_t pb = partial_bytes(c.k, split);
+    if (pb >= c.ws_bytes) return HIPBLAS_STATUS_ALLOC_FAILED;
+    const size_t ws_lib = c.ws_bytes - pb;
     std::vector<hipblasLtMatmulHeuristicResult_t> cand;
+    const bool d32 = split > 1 || c.k.d32;
     if (S.mode == 2) {
         std::vector<hipblasLtMatmulHeuristicResult_t> all;
         const Key &k = c.k;
         hipblasStatus_t s = hipblaslt_ext::getAllAlgos(
             S.handle, hipblaslt_ext::GemmType::HIPBLASLT_GEMM, k.tb ? HIPBLAS_OP_T : HIPBLAS_OP_N,
-            k.ta ? HIPBLAS_OP_T : HIPBLAS_OP_N, HIP_R_16BF, HIP_R_16BF, k.d32 ? HIP_R_32F : HIP_R_16BF,
-            k.d32 ? HIP_R_32F : HIP_R_16BF, HIPBLAS_COMPUTE_32F, all);
+            k.ta ? HIPBLAS_OP_T : HIPBLAS_OP_N, HIP_R_16BF, HIP_R_16BF, d32 ? HIP_R_32F : HIP_R_16BF,
+            d32 ? HIP_R_32F : HIP_R_16BF, HIPBLAS_COMPUTE_32F, all);
         if (s == HIPBLAS_STATUS_SUCCESS)
             for (auto &r : all) {
                 size_t need = 0;
                 const float one = 1.f, zero = 0.f;
                 if (hipblaslt_ext::matmulIsAlgoSupported(S.handle, p.desc, &one, p.la, p.lb, &zero, p.ld, p.ld, r.algo,
                                                          need) == HIPBLAS_STATUS_SUCCESS &&
-                    need <= c.ws_bytes) {
+                    need <= ws_lib) {
                     r.workspaceSize = need;
                     cand.push_back(r);
                 }
@@ -172,9 +239,9 @@ hipblasStatus_t choose(State &S, const Call &c, Problem &p, Choice &out) {
         hipblasLtMatmulPreference_t pref = nullptr;
         hipblasStatus_t s = hipblasLtMatmulPreferenceCreate(&pref);
         if (s != HIPBLAS_STATUS_SUCCESS) return s;
-        const uint64_t wsmax = c.ws_bytes;
+        const uint64_t wsmax = ws_lib;
         hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsmax, sizeof(wsmax));
-        const int want = S.mode == 0 ? 1 : S.candidates;
+        const int want = S.mode == 0 ? 1 : (split > 1 ? std::min(S.candidates, 12) : S.candidates);
         cand.resize(want);
         int got = 0;
         s = hipblasLtMatmulAlgoGetHeuristic(S.handle, p.desc, p.la, p.lb, p.ld, p.ld, pref, want, cand.data(), &got);
@@ -183,7 +250,8 @@ hipblasStatus_t choose(State &S, const Call &c, Problem &p, Choice &out) {
         cand.resize(std::max(got, 0));
         if (cand.empty()) return HIPBLAS_STATUS_NOT_SUPPORTED;
     }
-    if (cand.size() == 1 || S.mode == 0) {
+    out.split = split;
+    if (S.mode == 0 || (cand.size() == 1 && !must_time)) {
         out.algo = cand[0].algo;
         out.workspace = cand[0].workspaceSize;
         out.index = hipblaslt_ext::getIndexFromAlgo(out.algo);
@@ -197,13 +265,13 @@ hipblasStatus_t choose(State &S, const Call &c, Problem &p, Choice &out) {
     // coarse pass over everything, then a longer look at the best few
     std::vector<std::pair<float, size_t>> timed;
     for (size_t i = 0; i < cand.size(); ++i) {
-        const float us = time_algo(S, c, p, cand[i].algo, cand[i].workspaceSize, e0, e1, 2);
+        const float us = time_algo(S, c, p, cand[i].algo, cand[i].workspaceSize, split, e0, e1, 2);
         if (us > 0.f) timed.emplace_back(us, i);
     }
     std::sort(timed.begin(), timed.end());
     for (size_t j = 0; j < std::min<size_t>(timed.size(), 4); ++j) {
         const size_t i = timed[j].second;
-        const float us = time_algo(S, c, p, cand[i].algo, cand[i].workspaceSize, e0, e1, 8);
+        const float us = time_algo(S, c, p, cand[i].algo, cand[i].workspaceSize, split, e0, e1, 8);
         if (us > 0.f && (best < 0.f || us < best)) {
             best = us;
             best_i = i;
@@ -220,6 +288,41 @@ hipblasStatus_t choose(State &S, const Call &c, Problem &p, Choice &out) {
     return HIPBLAS_STATUS_SUCCESS;
 }
 
+// Slices worth trying: only reductions that are long and leave most of the chip without an output
+// tile; the partial products must fit the workspace next to the library's own scratch.
+std::vector<int> split_candidates(const State &S, const Call &c) {
+    std::vector<int> v{1};
+    const Key &k = c.k;
+    if (S.mode == 0 || c.bias || k.K < 4096 || k.N % 4) return v;
+    const int64_t tiles = ((k.M + 127) / 128) * ((k.N + 127) / 128);
+    if (tiles >= 256) return v;
+    for (int s = 2; s <= 64; s *= 2) {
+        if (k.K % s || k.K / s < 512 || tiles * s > 4096) break;
+        if (partial_bytes(k, s) + (8u << 20) > c.ws_bytes) break;
+        v.push_back(s);
+    }
+    return v;
+}
+
+hipblasStatus_t choose(State &S, const Call &c, Choice &out) {
+    const std::vector<int> splits = split_candidates(S, c);
+    hipblasStatus_t last = HIPBLAS_STATUS_NOT_SUPPORTED;
+    bool have = false;
+    for (int split : splits) {
+        Problem p;
+        hipblasStatus_t s = make_problem(c, p, split);
+        Choice ch;
+        if (s == HIPBLAS_STATUS_SUCCESS) s = choose_for_split(S, c, p, split, splits.size() > 1, ch);
+        if (s != HIPBLAS_STATUS_SUCCESS) {
+            last = s;
+            continue;
+        }
+        if (!have || (ch.us > 0.f && ch.us < out.us)) out = ch;
+        have = true;
+    }
+    return have ? HIPBLAS_STATUS_SUCCESS : last;
+}
+
 // An entry that came from text: look the algorithm up by index and make sure it fits this problem.
 bool resolve(State &S, const Call &c, Problem &p, Choice &ch) {
     std::vector<int> idx{ch.index};
@@ -229,7 +332,7 @@ bool resolve(State &S, const Call &c, Problem &p, Choice &ch) {
     size_t need = 0;
     const float one = 1.f, zero = 0.f;
     if (hipblaslt_ext::matmulIsAlgoSupported(S.handle, p.desc, &one, p.la, p.lb, &zero, p.ld, p.ld, res[0].algo, need) !=
-            HIPBLAS_STATUS_SUCCESS || need > c.ws_bytes)
+            HIPBLAS_STATUS_SUCCESS || need + partial_bytes(c.k, ch.split) > c.ws_bytes)
         return false;
     ch.algo = res[0].algo;
     ch.workspace = need;
@@ -276,29 +379,50 @@ int vah_gemm_bf16(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, con
     }
     Call c{{trans_a ? 1 : 0, trans_b ? 1 : 0, d_is_f32 ? 1 : 0, epilogue, bias_is_f32 ? 1 : 0, M, N, K, lda, ldb, ldd},
            A, B, bias, D, workspace, (size_t)workspace_bytes, (hipStream_t)stream};
-    Problem p;
-    hipblasStatus_t s = make_problem(c, p);
-    if (s != HIPBLAS_STATUS_SUCCESS) return fail(VAH_E_UNSUPPORTED, "%s: descriptor: %s", fn, status_name(s));
+    hipblasStatus_t s = HIPBLAS_STATUS_SUCCESS;
     LaunchScope scope("gemm_bf16", (M * K + K * N) * 2 + M * N * (d_is_f32 ? 4 : 2), c.st);
     auto it = S.table.find(c.k);
-    if (it != S.table.end() && !it->second.resolved && !resolve(S, c, p, it->second)) {
-        S.table.erase(it);
-        it = S.table.end();
+    if (it != S.table.end() && !it->second.resolved) {
+        Problem p;
+        const int split = it->second.split;
+        if (split < 1 || K % split || make_problem(c, p, split) != HIPBLAS_STATUS_SUCCESS ||
+            partial_bytes(c.k, split) >= c.ws_bytes || !resolve(S, c, p, it->second)) {
+            S.table.erase(it);
+            it = S.table.end();
+        }
     }
     if (it == S.table.end()) {
         Choice ch;
-        s = choose(S, c, p, ch);
+        s = choose(S, c, ch);
         if (s != HIPBLAS_STATUS_SUCCESS)
             return fail(VAH_E_UNSUPPORTED, "%s: no algorithm for %lldx%lldx%lld ta=%d tb=%d f32=%d epi=%d: %s", fn,
                         (long long)M, (long long)N, (long long)K, trans_a, trans_b, d_is_f32, epilogue, status_name(s));
         it = S.table.emplace(c.k, ch).first;
     }
-    s = run(S, c, p, it->second.algo, it->second.workspace);
+    Problem p;
+    s = make_problem(c, p, it->second.split);
+    if (s != HIPBLAS_STATUS_SUCCESS) return fail(VAH_E_UNSUPPORTED, "%s: descriptor: %s", fn, status_name(s));
+    s = run(S, c, p, it->second.algo, it->second.workspace, it->second.split);
     if (s != HIPBLAS_STATUS_SUCCESS) return fail(VAH_E_UNSUPPORTED, "%s: hipblasLtMatmul: %s", fn, status_name(s));
     return check_launch(fn);
 }
 
-// One line per problem: "ta tb d32 epi bias32 M N K lda ldb ldd index us".
+// Version of the hipBLASLt build behind the dispatcher (algorithm indices of a dumped table are only
+// meaningful for the same build); < 0 on error.
+int64_t vah_gemm_library_version(void) {
+    using namespace vah;
+    clear_error();
+    State &S = state();
+    std::lock_guard<std::mutex> lock(S.mu);
+    if (!S.handle && hipblasLtCreate(&S.handle) != HIPBLAS_STATUS_SUCCESS)
+        return fail(VAH_E_UNSUPPORTED, "vah_gemm_library_version: hipblasLtCreate failed");
+    int v = 0;
+    if (hipblasLtGetVersion(S.handle, &v) != HIPBLAS_STATUS_SUCCESS)
+        return fail(VAH_E_UNSUPPORTED, "vah_gemm_library_version: hipblasLtGetVersion failed");
+    return v;
+}
+
+// One line per problem: "ta tb d32 epi bias32 M N K lda ldb ldd index split us".
 int64_t vah_gemm_table_dump(char *buf, int64_t cap) {
     using namespace vah;
     State &S = state();
@@ -307,7 +431,8 @@ int64_t vah_gemm_table_dump(char *buf, int64_t cap) {
     for (auto &kv : S.table) {
         const Key &k = kv.first;
         os << k.ta << ' ' << k.tb << ' ' << k.d32 << ' ' << k.epi << ' ' << k.bias32 << ' ' << k.M << ' ' << k.N << ' '
-           << k.K << ' ' << k.lda << ' ' << k.ldb << ' ' << k.ldd << ' ' << kv.second.index << ' ' << kv.second.us << '\n';
+           << k.K << ' ' << k.lda << ' ' << k.ldb << ' ' << k.ldd << ' ' << kv.second.index << ' ' << kv.second.split << ' '
+           << kv.second.us << '\n';
     }
     const std::string t = os.str();
     if (buf && cap > 0) {
@@ -332,7 +457,7 @@ int vah_gemm_table_load(const char *text) {
         std::istringstream ls(line);
         Key k;
         Choice ch;
-        if (!(ls >> k.ta >> k.tb >> k.d32 >> k.epi >> k.bias32 >> k.M >> k.N >> k.K >> k.lda >> k.ldb >> k.ldd >> ch.index >> ch.us))
+        if (!(ls >> k.ta >> k.tb >> k.d32 >> k.epi >> k.bias32 >> k.M >> k.N >> k.K >> k.lda >> k.ldb >> k.ldd >> ch.index >> ch.split >> ch.us))
             return fail(VAH_E_SHAPE, "vah_gemm_table_load: malformed line '%s'", line.c_str());
         ch.resolved = false;
         S.table[k] = ch;

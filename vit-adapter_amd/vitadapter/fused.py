@@ -157,7 +157,8 @@ def refresh_linear_copies(module):
 
 _GEMM_WS_BYTES = 32 << 20
 WGRAD_F32 = os.environ.get('VAH_LINEAR_WGRAD', 'f32') == 'f32'
-GEMM_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tuning', 'gemm_table_mi355x.txt')
+GEMM_TABLE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tuning',
+                          'gemm_table_mi355x_base_det_1024.txt')
 
 
 def _configure_gemm():
@@ -192,14 +193,17 @@ def gemm_bf16(a, b, trans_a=False, trans_b=False, out_dtype=torch.bfloat16, bias
         return d
     if K == 0:
         return d.zero_()
-    ws = torch.empty(_GEMM_WS_BYTES, dtype=torch.uint8, device=a.device)
+    ws_bytes = _GEMM_WS_BYTES
+    if bias is None and K >= 4096:       # room for the fp32 partial products of a split-K run
+        ws_bytes += min(64 * M * N * 4, 160 << 20)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
     epilogue = _vah.GEMM_EPI_BIAS if bias is not None else _vah.GEMM_EPI_NONE
     with torch.cuda.device(a.device):
         _vah.check(_vah.lib.vah_gemm_bf16(
             int(trans_a), int(trans_b), M, N, K, a.data_ptr(), a.shape[1], b.data_ptr(), b.shape[1],
             d.data_ptr(), N, int(out_dtype == torch.float32), epilogue,
             bias.data_ptr() if bias is not None else None,
-            int(bias is not None and bias.dtype == torch.float32), ws.data_ptr(), _GEMM_WS_BYTES, _stream(a)), 'gemm_bf16')
+            int(bias is not None and bias.dtype == torch.float32), ws.data_ptr(), ws_bytes, _stream(a)), 'gemm_bf16')
     return d
 
 
