@@ -50,6 +50,9 @@ def parse():
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' lets several ranks share one GPU for a functional rehearsal of the "
                          "N>1 path on a 1-GPU box (not a performance mode)")
+    ap.add_argument('--profile-kernels', default='msda_',
+                    help='HIP-event timing inside the timed region for the library entry points whose name '
+                         'starts with this prefix ("" = all of them, costs ~2 %%; "none" = no events)')
     ap.add_argument('--gemm-tuning', default='file', choices=['file', 'off', 'tune'],
                     help="hipBLASLt/rocBLAS solution selection through torch TunableOp: 'file' loads the "
                          "committed selections (no tuning at run time), 'tune' re-tunes and rewrites them")
@@ -211,7 +214,7 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
-    _vah.prof_enable(True)
+    _vah.prof_enable(True, args.profile_kernels)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()

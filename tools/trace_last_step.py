@@ -23,6 +23,7 @@ def main():
     ap.add_argument('trace')
     ap.add_argument('--top', type=int, default=70)
     ap.add_argument('--marker', default='multi_tensor_apply_kernel')
+    ap.add_argument('--gaps', type=int, default=0, help='also list the N largest idle gaps between kernels')
     args = ap.parse_args()
     rows = list(csv.DictReader(open(args.trace)))
     rows.sort(key=lambda r: int(r['Start_Timestamp']))
@@ -50,6 +51,22 @@ def main():
     print(f'{"kernel":110s} {"calls":>6s} {"avg us":>9s} {"total ms":>9s} {"share":>6s}')
     for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:args.top]:
         print(f'{k:110s} {c:6d} {t / c:9.1f} {t / 1e3:9.3f} {100 * t / 1e3 / busy:5.1f}%')
+    if args.gaps:
+        gaps = []
+        for a, b in zip(step, step[1:]):
+            g = (int(b['Start_Timestamp']) - int(a['End_Timestamp'])) / 1e3
+            if g > 0:
+                gaps.append((g, short(a['Kernel_Name'])[:60], short(b['Kernel_Name'])[:60]))
+        tot = sum(g for g, _, _ in gaps) / 1e3
+        print(f'idle between kernels: {tot:.2f} ms in {len(gaps)} gaps; gaps > 20 us: '
+              f'{sum(g for g, _, _ in gaps if g > 20) / 1e3:.2f} ms')
+        by_next = defaultdict(lambda: [0, 0.0])
+        for g, a, b in gaps:
+            by_next[b][0] += 1
+            by_next[b][1] += g
+        print('idle time by the kernel that follows the gap:')
+        for k, (c, t) in sorted(by_next.items(), key=lambda kv: -kv[1][1])[:args.gaps]:
+            print(f'  {k:60s} {c:5d} gaps {t / 1e3:8.3f} ms  avg {t / c:7.1f} us')
 
 
 if __name__ == '__main__':

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -30,6 +30,8 @@ lib.vah_abi_version.restype = ctypes.c_int
 lib.vah_last_error.restype = ctypes.c_char_p
 lib.vah_prof_enable.argtypes = [ctypes.c_int]
 lib.vah_prof_enable.restype = ctypes.c_int
+lib.vah_prof_filter.argtypes = [ctypes.c_char_p]
+lib.vah_prof_filter.restype = ctypes.c_int
 lib.vah_prof_report.argtypes = [ctypes.c_char_p, _i64]
 lib.vah_prof_report.restype = _i64
 for _sfx in ('f32', 'f64'):
@@ -107,7 +109,7 @@ if lib.vah_abi_version() != ABI_VERSION:
 
 # every symbol include/vitadapter_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = (
-    'vah_abi_version', 'vah_last_error', 'vah_prof_enable', 'vah_prof_report',
+    'vah_abi_version', 'vah_last_error', 'vah_prof_enable', 'vah_prof_filter', 'vah_prof_report',
     'vah_msda_forward_f32', 'vah_msda_forward_f64',
     'vah_msda_backward_f32', 'vah_msda_backward_f64',
     'vah_msda_forward_win_f32', 'vah_msda_backward_win_f32',
@@ -128,7 +130,9 @@ def check(rc, what):
         raise RuntimeError('%s failed (code %d): %s' % (what, rc, msg))
 
 
-def prof_enable(on):
+def prof_enable(on, prefix=''):
+    """Time the launches of the entry points whose profile name starts with ``prefix``."""
+    lib.vah_prof_filter(prefix.encode())
     lib.vah_prof_enable(1 if on else 0)
 
 

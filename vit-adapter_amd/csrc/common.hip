@@ -38,6 +38,7 @@ struct Rec {
 
 static std::mutex g_mu;
 static bool g_on = false;
+static char g_prefix[64] = "";                  // only scopes whose name starts with this are timed
 static std::vector<Rec> g_recs;                 // live records of the current collection
 static std::vector<hipEvent_t> g_pool;          // recycled events
 
@@ -64,7 +65,7 @@ LaunchScope::LaunchScope(const char *name, int64_t bytes, hipStream_t stream)
     : slot_(-1), stream_(stream) {
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_on) return;
+    if (!g_on || strncmp(name, g_prefix, strlen(g_prefix)) != 0) return;
     Rec r{name, bytes, take_event(), take_event()};
     if (!r.start || !r.stop) return;
     (void)hipEventRecord(r.start, stream);
@@ -82,7 +83,7 @@ LaunchScope::~LaunchScope() {
 
 extern "C" {
 
-int vah_abi_version(void) { return 14; }
+int vah_abi_version(void) { return 15; }
 
 const char *vah_last_error(void) { return vah::g_err; }
 
@@ -90,6 +91,12 @@ int vah_prof_enable(int on) {
     std::lock_guard<std::mutex> lk(vah::g_mu);
     if (on) vah::recycle_all();
     vah::g_on = on != 0;
+    return VAH_OK;
+}
+
+int vah_prof_filter(const char *prefix) {
+    std::lock_guard<std::mutex> lk(vah::g_mu);
+    snprintf(vah::g_prefix, sizeof(vah::g_prefix), "%s", prefix ? prefix : "");
     return VAH_OK;
 }
 
