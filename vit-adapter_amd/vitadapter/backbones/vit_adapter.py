@@ -147,7 +147,7 @@ class ViTAdapter(TIMMVisionTransformer):
             # f1 = norm1(up(c2) + c1 + interp(x1, 4)), f2 = norm2(c2 + interp(x2, 2)), f3 = norm3(c3 + x3):
             # sum, upsampling and batch norm in one pair of passes (csrc/tail_ops.hip); off the bf16
             # GPU path fused.bn_tail evaluates exactly the reference expression
-            c4 = c4 + F.interpolate(x4, scale_factor=0.5, mode='bilinear', align_corners=False)
+            c4 = c4 + fused.halve(x4)
             return [fused.bn_tail(self.norm1, self.up(c2), c1, x1, 4), fused.bn_tail(self.norm2, c2, None, x2, 2),
                     fused.bn_tail(self.norm3, c3, None, x3, 1), self.norm4(c4)]
         c1 = self.up(c2) + c1

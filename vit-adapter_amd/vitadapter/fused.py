@@ -461,6 +461,17 @@ class _BNTail(torch.autograd.Function):
         return da, db, dx, dweight, dbias, None, None
 
 
+def halve(x):
+    """``F.interpolate(x, scale_factor=0.5, mode='bilinear', align_corners=False)`` (vit_adapter.py:121).
+    With even H, W the taps are (0.5, 0.5) in both directions: the 2x2 mean.  torch's bilinear
+    kernel parallelises over output pixels only (706 us for 2x768x32x32 on MI355X); on the bf16
+    GPU path the mean is taken with avg_pool2d, elsewhere the reference call is kept."""
+    if (ENABLED['bn_tail'] and x.is_cuda and _bf16_autocast() and x.dim() == 4 and x.shape[2] % 2 == 0
+            and x.shape[3] % 2 == 0):
+        return F.avg_pool2d(x.float(), 2)
+    return F.interpolate(x, scale_factor=0.5, mode='bilinear', align_corners=False)
+
+
 def bn_tail(norm, a, b=None, x=None, scale=1):
     """``norm(a + b + F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=False))``
     for a (Sync)BatchNorm2d ``norm`` - the output tail of the backbone (ref vit_adapter.py:106-127);
