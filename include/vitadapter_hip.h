@@ -234,6 +234,19 @@ int vah_layernorm_fwd_f32_bf16(const float *x, const float *w, const float *b, i
 int vah_layernorm_bwd_f32_bf16(const float *x, const void *g_bf16, const float *w, const float *mean,
                                const float *rstd, const float *gres, int64_t rows, int64_t C,
                                float *dx, float *dw, float *db, float *ws /* K = 2C */, void *stream);
+/* Residual update + LayerNorm in one pass (the pattern  x = x + drop_path(gamma * f(..)); h = norm(x)
+ * of consecutive sub-blocks, base/vit.py:301-306, adapter_modules.py:112-117):
+ *   fwd:  t = x + sc[b] * gamma * z (fp32, written),  h = LayerNorm(t) (bf16)
+ *   bwd:  dt = gt + LayerNorm'(gh)  (= dx),  dz = sc * gamma * dt (bf16),  dgamma = sum sc * dt * z, dw, db
+ * x, t (batch, rows_per_batch, C) fp32; z bf16; gamma (C), sc (batch), gt optional (NULL).
+ * ws: vah_reduce_ws_floats(2 * C). */
+int vah_residual_layernorm_fwd(const float *x, const void *z_bf16, const float *gamma, const float *sc,
+                               int64_t batch, int64_t rows_per_batch, int64_t C, const float *w, const float *b,
+                               float eps, float *t, void *h_bf16, float *mean, float *rstd, void *stream);
+int vah_residual_layernorm_bwd(const float *t, const void *gh_bf16, const float *w, const float *mean,
+                               const float *rstd, const float *gt, const void *z_bf16, const float *gamma,
+                               const float *sc, int64_t batch, int64_t rows_per_batch, int64_t C, float *dt,
+                               void *dz_bf16, float *dgamma, float *dw, float *db, float *ws, void *stream);
 /* out[c] = sum_r g[r][c] of a bf16 (rows, C) matrix, C % 8 == 0: the bias gradient of nn.Linear
  * (what autograd computes as grad_output.sum(0)); ws K = C. */
 int vah_colsum_bf16(const void *g_bf16, int64_t rows, int64_t C, float *out, float *ws, void *stream);

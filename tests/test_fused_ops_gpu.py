@@ -309,3 +309,53 @@ def test_bn_tail_matches_reference_expression(N, C, H, W, scale, with_b, a_bf16,
     _close(bn.running_mean, ref_bn.running_mean, 1e-5, 'running_mean')
     _close(bn.running_var, ref_bn.running_var, 1e-5, 'running_var')
     assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked)
+
+
+@pytest.mark.parametrize('with_gamma,prob,C', [(True, 0.3, 768), (False, 0.0, 192), (True, 0.0, 1024), (False, 0.5, 64)])
+def test_residual_ln_pair(with_gamma, prob, C):
+    """fused.residual_ln = (t, norm(t)) with t = x + drop_path(gamma * z): forward and all gradients
+    against the two separate ops in fp32, with both outputs feeding the loss."""
+    from vitadapter import fused
+    from vitadapter.backbones.vit import DropPath
+    torch.manual_seed(8)
+    B, N = 3, 157
+    ln = torch.nn.LayerNorm(C, eps=1e-6).cuda()
+    with torch.no_grad():
+        ln.weight.normal_(1, 0.2)
+        ln.bias.normal_(0, 0.2)
+    x = torch.randn(B, N, C, device='cuda', requires_grad=True)
+    z = torch.randn(B, N, C, device='cuda').to(torch.bfloat16).requires_grad_(True)
+    gamma = (torch.randn(C, device='cuda') * 0.5).requires_grad_(True) if with_gamma else None
+    dp = DropPath(prob).train()
+    gt = torch.randn(B, N, C, device='cuda')
+    gh = torch.randn(B, N, C, device='cuda').to(torch.bfloat16)
+    torch.manual_seed(9)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        t, h = fused.residual_ln(x, z, gamma, dp, ln)
+    assert type(t.grad_fn).__name__ == '_ResidualLNBackward' and h.dtype == torch.bfloat16
+    torch.autograd.backward([t, h], [gt, gh])
+    got = [x.grad.clone(), z.grad.clone(), ln.weight.grad.clone(), ln.bias.grad.clone()] + \
+        ([gamma.grad.clone()] if with_gamma else [])
+    torch.manual_seed(9)
+    keep = 1 - prob
+    s = x.new_empty((B,)).bernoulli_(keep).div_(keep) if prob > 0 else torch.ones(B, device='cuda')
+    x2, z2 = x.detach().clone().requires_grad_(True), z.detach().float().requires_grad_(True)
+    g2 = gamma.detach().clone().requires_grad_(True) if with_gamma else None
+    ln.zero_grad()
+    tr = x2 + ((g2 * z2) if with_gamma else z2) * s.view(B, 1, 1)
+    hr = ln(tr)
+    torch.autograd.backward([tr, hr], [gt, gh.float()])
+    _close(t, tr, 1e-6, 't')
+    _close(h, hr, 1e-2, 'h')
+    _close(got[0], x2.grad, 1e-4, 'dx')
+    _close(got[1], z2.grad, 1e-2, 'dz (bf16)')
+    _close(got[2], ln.weight.grad, 1e-3, 'dw')
+    _close(got[3], ln.bias.grad, 1e-3, 'db')
+    if with_gamma:
+        _close(got[4], g2.grad, 1e-3, 'dgamma')
+    # only the residual output used
+    x.grad = z.grad = None
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        t, h = fused.residual_ln(x, z, gamma, None, ln)
+    t.backward(gt)
+    _close(x.grad, gt, 1e-7, 'dx (t only)')

@@ -29,11 +29,21 @@ constexpr int kMaxVecAll = 8;    // float4 groups per lane: C <= 64 * 4 * 8 = 20
 // ---------------------------------------------------------------------------------------
 // LayerNorm forward: one wave per row
 // ---------------------------------------------------------------------------------------
+// With a residual update fused in front (z != NULL):  t = x + sc[b] * gamma * z  is written to `sum`
+// (fp32) and normalised in the same pass - the pattern  x = x + drop_path(gamma * f(..)); h = norm(x)
+// of consecutive sub-blocks (base/vit.py:301-306), which otherwise re-reads x from HBM.
+struct ResidualIn {
+    const __bf16 *z;          // NULL: plain LayerNorm of x
+    const float *gamma, *sc;  // optional
+    int64_t rows_per_batch;
+    float *sum;               // t out (forward) / unused (backward)
+};
+
 template <int kMaxVec>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x,
                                                      const float *__restrict__ w,
                                                      const float *__restrict__ b, int64_t rows, int C,
-                                                     float eps, __bf16 *__restrict__ y,
+                                                     float eps, ResidualIn res, __bf16 *__restrict__ y,
                                                      float *__restrict__ mean, float *__restrict__ rstd) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -42,11 +52,24 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
     const float *xr = x + row * C;
     float4 v[kMaxVec];
     float s = 0.f;
+    const float sb = (res.z && res.sc) ? res.sc[row / res.rows_per_batch] : 1.f;
 #pragma unroll
     for (int j = 0; j < kMaxVec; ++j) {
         const int i = lane + 64 * j;
         v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < nvec) v[j] = *reinterpret_cast<const float4 *>(xr + 4 * i);
+        if (i < nvec) {
+            v[j] = *reinterpret_cast<const float4 *>(xr + 4 * i);
+            if (res.z) {
+                const bf16x4 zv = *reinterpret_cast<const bf16x4 *>(res.z + row * C + 4 * i);
+                float4 gm = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (res.gamma) gm = *reinterpret_cast<const float4 *>(res.gamma + 4 * i);
+                v[j].x += sb * gm.x * (float)zv[0];
+                v[j].y += sb * gm.y * (float)zv[1];
+                v[j].z += sb * gm.z * (float)zv[2];
+                v[j].w += sb * gm.w * (float)zv[3];
+                *reinterpret_cast<float4 *>(res.sum + row * C + 4 * i) = v[j];
+            }
+        }
         s += v[j].x + v[j].y + v[j].z + v[j].w;
     }
     const float mu = wave_sum(s) / (float)C;
@@ -92,7 +115,8 @@ constexpr int kMaxParts = 512;
 // chain: measured 235 us per call, 18 ms per training step).
 __global__ __launch_bounds__(256) void finalize_partials(const float *__restrict__ part, int nparts,
                                                          int K, float *__restrict__ out0, int K0,
-                                                         float *__restrict__ out1) {
+                                                         float *__restrict__ out1, int K1,
+                                                         float *__restrict__ out2) {
     __shared__ float s_acc[8][32];
     const int col = threadIdx.x & 31, pl = threadIdx.x >> 5;
     const int k = blockIdx.x * 32 + col;
@@ -112,7 +136,9 @@ __global__ __launch_bounds__(256) void finalize_partials(const float *__restrict
 #pragma unroll
         for (int u = 0; u < 8; ++u) t += s_acc[u][col];
         if (k < K0) out0[k] = t;
-        else if (out1) out1[k - K0] = t;
+        else if (k - K0 < K1) {
+            if (out1) out1[k - K0] = t;
+        } else if (out2) out2[k - K0 - K1] = t;
     }
 }
 
@@ -125,16 +151,23 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ x
                                                      const float *__restrict__ mean,
                                                      const float *__restrict__ rstd,
                                                      const float *__restrict__ gres, int64_t rows, int C,
+                                                     ResidualIn res, __bf16 *__restrict__ dz,
                                                      float *__restrict__ dx, float *__restrict__ part) {
-    extern __shared__ __attribute__((aligned(16))) float s_red[];      // [4][2C]
+    // partial row: [dw | db] or, with a fused residual update in front, [dw | db | dgamma]
+    extern __shared__ __attribute__((aligned(16))) float s_red[];      // [4][ncol * C]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nvec = C >> 2;
-    float4 ww[kMaxVec], aw[kMaxVec], ab[kMaxVec];
+    const int ncol = res.z ? 3 : 2;
+    float4 ww[kMaxVec], aw[kMaxVec], ab[kMaxVec], ag[kMaxVec], gm[kMaxVec];
 #pragma unroll
     for (int j = 0; j < kMaxVec; ++j) {
         const int i = lane + 64 * j;
-        ww[j] = aw[j] = ab[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < nvec) ww[j] = *reinterpret_cast<const float4 *>(w + 4 * i);
+        ww[j] = aw[j] = ab[j] = ag[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gm[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (i < nvec) {
+            ww[j] = *reinterpret_cast<const float4 *>(w + 4 * i);
+            if (res.z && res.gamma) gm[j] = *reinterpret_cast<const float4 *>(res.gamma + 4 * i);
+        }
     }
     const float invC = 1.f / (float)C;
     // Two rows per wave in flight: with <= 512 workgroups a wave walks only a few rows, and one row's
@@ -145,13 +178,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ x
         int64_t rws[2] = {row, row + stride};
         const int nrow = rws[1] < rows ? 2 : 1;
         float4 xv[2][kMaxVec], rv[2][kMaxVec];
-        bf16x4 gv[2][kMaxVec];
-        float mu[2], rs[2];
+        bf16x4 gv[2][kMaxVec], zv[2][kMaxVec];
+        float mu[2], rs[2], sb[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             if (u >= nrow) rws[u] = row;                 // harmless duplicate loads, results unused
             mu[u] = mean[rws[u]];
             rs[u] = rstd[rws[u]];
+            sb[u] = (res.z && res.sc) ? res.sc[rws[u] / res.rows_per_batch] : 1.f;
 #pragma unroll
             for (int j = 0; j < kMaxVec; ++j) {
                 const int i = lane + 64 * j;
@@ -160,6 +194,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ x
                     gv[u][j] = *reinterpret_cast<const bf16x4 *>(g + rws[u] * C + 4 * i);
                     rv[u][j] = gres ? *reinterpret_cast<const float4 *>(gres + rws[u] * C + 4 * i)
                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (res.z) zv[u][j] = *reinterpret_cast<const bf16x4 *>(res.z + rws[u] * C + 4 * i);
                 }
             }
         }
@@ -199,9 +234,22 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ x
                 if (i < nvec) {
                     const float4 r = rv[u][j];           // gradient of the residual branch of x (or 0)
                     const float k = rs[u];
-                    *reinterpret_cast<float4 *>(dr + 4 * i) =
+                    const float4 d =
                         make_float4(r.x + k * (gw[j].x - m1 - xh[j].x * m2), r.y + k * (gw[j].y - m1 - xh[j].y * m2),
                                     r.z + k * (gw[j].z - m1 - xh[j].z * m2), r.w + k * (gw[j].w - m1 - xh[j].w * m2));
+                    *reinterpret_cast<float4 *>(dr + 4 * i) = d;
+                    if (res.z) {                          // t = x + sc * gamma * z in front: dz, dgamma from dt = d
+                        bf16x4 o;
+                        o[0] = (__bf16)(sb[u] * gm[j].x * d.x);
+                        o[1] = (__bf16)(sb[u] * gm[j].y * d.y);
+                        o[2] = (__bf16)(sb[u] * gm[j].z * d.z);
+                        o[3] = (__bf16)(sb[u] * gm[j].w * d.w);
+                        *reinterpret_cast<bf16x4 *>(dz + rws[u] * C + 4 * i) = o;
+                        ag[j].x += sb[u] * d.x * (float)zv[u][j][0];
+                        ag[j].y += sb[u] * d.y * (float)zv[u][j][1];
+                        ag[j].z += sb[u] * d.z * (float)zv[u][j][2];
+                        ag[j].w += sb[u] * d.w * (float)zv[u][j][3];
+                    }
                 }
             }
         }
@@ -210,14 +258,15 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ x
     for (int j = 0; j < kMaxVec; ++j) {
         const int i = lane + 64 * j;
         if (i < nvec) {
-            *reinterpret_cast<float4 *>(s_red + wv * 2 * C + 4 * i) = aw[j];
-            *reinterpret_cast<float4 *>(s_red + wv * 2 * C + C + 4 * i) = ab[j];
+            *reinterpret_cast<float4 *>(s_red + wv * ncol * C + 4 * i) = aw[j];
+            *reinterpret_cast<float4 *>(s_red + wv * ncol * C + C + 4 * i) = ab[j];
+            if (res.z) *reinterpret_cast<float4 *>(s_red + wv * ncol * C + 2 * C + 4 * i) = ag[j];
         }
     }
     __syncthreads();
-    float *pr = part + (int64_t)blockIdx.x * 2 * C;
-    for (int k = threadIdx.x; k < 2 * C; k += 256)
-        pr[k] = s_red[k] + s_red[2 * C + k] + s_red[4 * C + k] + s_red[6 * C + k];
+    const int K = ncol * C;
+    float *pr = part + (int64_t)blockIdx.x * K;
+    for (int k = threadIdx.x; k < K; k += 256) pr[k] = s_red[k] + s_red[K + k] + s_red[2 * K + k] + s_red[3 * K + k];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -482,20 +531,43 @@ inline unsigned grid_for(int64_t work_items, int per_block) {
 
 extern "C" {
 
+static int ln_fwd_launch(const char *fn, const float *x, const float *w, const float *b, int64_t rows, int64_t C,
+                         float eps, vah::ResidualIn res, void *y, float *mean, float *rstd, void *stream);
+
 int vah_layernorm_fwd_f32_bf16(const float *x, const float *w, const float *b, int64_t rows,
                                int64_t C, float eps, void *y, float *mean, float *rstd, void *stream) {
+    return ln_fwd_launch("vah_layernorm_fwd_f32_bf16", x, w, b, rows, C, eps, vah::ResidualIn{nullptr, nullptr, nullptr, 1, nullptr},
+                         y, mean, rstd, stream);
+}
+
+// t = x + sc[b] * gamma * z (written to t, fp32), h = LayerNorm(t) (bf16): vah_scale_residual_fwd and
+// vah_layernorm_fwd_f32_bf16 in one pass over the rows.  gamma, sc optional.
+int vah_residual_layernorm_fwd(const float *x, const void *z, const float *gamma, const float *sc, int64_t batch,
+                               int64_t rows_per_batch, int64_t C, const float *w, const float *b, float eps, float *t,
+                               void *h, float *mean, float *rstd, void *stream) {
+    using namespace vah;
+    const char *fn = "vah_residual_layernorm_fwd";
+    clear_error();
+    if (batch < 0 || rows_per_batch < 0) return fail(VAH_E_SHAPE, "%s: bad dims", fn);
+    if (batch * rows_per_batch > 0 && (!z || !t)) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if (((uintptr_t)gamma | (uintptr_t)t) % 16 || (uintptr_t)z % 8) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    return ln_fwd_launch(fn, x, w, b, batch * rows_per_batch, C, eps,
+                         ResidualIn{(const __bf16 *)z, gamma, sc, std::max<int64_t>(rows_per_batch, 1), t}, h, mean, rstd, stream);
+}
+
+static int ln_fwd_launch(const char *fn, const float *x, const float *w, const float *b, int64_t rows, int64_t C,
+                         float eps, vah::ResidualIn res, void *y, float *mean, float *rstd, void *stream) {
     using namespace vah;
     clear_error();
-    const char *fn = "vah_layernorm_fwd_f32_bf16";
     if (rows < 0 || C < 4 || C % 4 || C > 64 * 4 * kMaxVecAll) return fail(VAH_E_SHAPE, "%s: C=%lld unsupported", fn, (long long)C);
     if (rows == 0) return VAH_OK;
     if (!x || !w || !b || !y || !mean || !rstd) return fail(VAH_E_NULL, "%s: null pointer", fn);
     if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)b) % 16 || (uintptr_t)y % 8) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
     hipStream_t st = (hipStream_t)stream;
-    LaunchScope scope("layernorm_fwd", rows * C * 6, st);
+    LaunchScope scope(res.z ? "residual_layernorm_fwd" : "layernorm_fwd", rows * C * (res.z ? 12 : 6), st);
 #define VAH_LN_FWD(NV)                                                                          \
     hipLaunchKernelGGL(ln_fwd_kernel<NV>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, w, b, \
-                       rows, (int)C, eps, (__bf16 *)y, mean, rstd)
+                       rows, (int)C, eps, res, (__bf16 *)y, mean, rstd)
     if (C <= 256) VAH_LN_FWD(1);
     else if (C <= 512) VAH_LN_FWD(2);
     else if (C <= 1024) VAH_LN_FWD(4);
@@ -506,38 +578,67 @@ int vah_layernorm_fwd_f32_bf16(const float *x, const float *w, const float *b, i
 
 int64_t vah_reduce_ws_floats(int64_t K) { return (int64_t)vah::kMaxParts * K; }
 
-// ws: vah_reduce_ws_floats(2*C) floats of scratch.  dw, db are overwritten.
-int vah_layernorm_bwd_f32_bf16(const float *x, const void *g, const float *w, const float *mean,
-                               const float *rstd, const float *gres, int64_t rows, int64_t C, float *dx,
-                               float *dw, float *db, float *ws, void *stream) {
+static int ln_bwd_launch(const char *fn, const float *x, const void *g, const float *w, const float *mean,
+                         const float *rstd, const float *gres, int64_t rows, int64_t C, vah::ResidualIn res, void *dz,
+                         float *dx, float *dw, float *db, float *dgamma, float *ws, void *stream) {
     using namespace vah;
     clear_error();
-    const char *fn = "vah_layernorm_bwd_f32_bf16";
     if (rows < 0 || C < 4 || C % 4 || C > 64 * 4 * kMaxVecAll) return fail(VAH_E_SHAPE, "%s: C=%lld unsupported", fn, (long long)C);
     if (!dw || !db || !ws) return fail(VAH_E_NULL, "%s: null pointer", fn);
     hipStream_t st = (hipStream_t)stream;
     if (rows == 0) {
         (void)hipMemsetAsync(dw, 0, C * 4, st);
         (void)hipMemsetAsync(db, 0, C * 4, st);
+        if (dgamma) (void)hipMemsetAsync(dgamma, 0, C * 4, st);
         return VAH_OK;
     }
     if (!x || !g || !w || !mean || !rstd || !dx) return fail(VAH_E_NULL, "%s: null pointer", fn);
     if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)dx | (uintptr_t)gres) % 16 || (uintptr_t)g % 8) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    const int ncol = res.z ? 3 : 2;
     int64_t nblocks = (rows + 3) / 4;
-    if (nblocks > kMaxParts) nblocks = kMaxParts;
-    const size_t smem = (size_t)8 * C * sizeof(float);
-    LaunchScope scope("layernorm_bwd", rows * C * 10, st);
+    nblocks = std::min<int64_t>(nblocks, kMaxParts * 2 / ncol);          // the scratch holds kMaxParts * 2C floats
+    const size_t smem = (size_t)4 * ncol * C * sizeof(float);
+    LaunchScope scope(res.z ? "residual_layernorm_bwd" : "layernorm_bwd", rows * C * (res.z ? 18 : 10), st);
 #define VAH_LN_BWD(NV)                                                                          \
     hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3((unsigned)nblocks), dim3(256), smem, st, x,      \
-                       (const __bf16 *)g, w, mean, rstd, gres, rows, (int)C, dx, ws)
+                       (const __bf16 *)g, w, mean, rstd, gres, rows, (int)C, res, (__bf16 *)dz, dx, ws)
+    if (smem > 64 * 1024) return fail(VAH_E_SHAPE, "%s: C too large for the fused form", fn);
     if (C <= 256) VAH_LN_BWD(1);
     else if (C <= 512) VAH_LN_BWD(2);
     else if (C <= 1024) VAH_LN_BWD(4);
     else VAH_LN_BWD(8);
 #undef VAH_LN_BWD
-    hipLaunchKernelGGL(finalize_partials, dim3((unsigned)((2 * C + 31) / 32)), dim3(256), 0, st, ws,
-                       (int)nblocks, (int)(2 * C), dw, (int)C, db);
+    // partial row = [dw | db | dgamma]
+    hipLaunchKernelGGL(finalize_partials, dim3((unsigned)((ncol * C + 31) / 32)), dim3(256), 0, st, ws,
+                       (int)nblocks, (int)(ncol * C), dw, (int)C, db, (int)C, dgamma);
     return check_launch(fn);
+}
+
+// ws: vah_reduce_ws_floats(2*C) floats of scratch.  dw, db are overwritten.
+int vah_layernorm_bwd_f32_bf16(const float *x, const void *g, const float *w, const float *mean,
+                               const float *rstd, const float *gres, int64_t rows, int64_t C, float *dx,
+                               float *dw, float *db, float *ws, void *stream) {
+    return ln_bwd_launch("vah_layernorm_bwd_f32_bf16", x, g, w, mean, rstd, gres, rows, C,
+                         vah::ResidualIn{nullptr, nullptr, nullptr, 1, nullptr}, nullptr, dx, dw, db, nullptr, ws, stream);
+}
+
+// Backward of vah_residual_layernorm_fwd: dt = gt + LayerNorm'(gh) (the gradient of x as well),
+// dz = sc * gamma * dt (bf16), dgamma = sum sc * dt * z, dw, db.  gt (gradient of t along the residual
+// stream) and gamma / sc / dgamma optional.  ws: vah_reduce_ws_floats(2*C).
+int vah_residual_layernorm_bwd(const float *t, const void *gh, const float *w, const float *mean, const float *rstd,
+                               const float *gt, const void *z, const float *gamma, const float *sc, int64_t batch,
+                               int64_t rows_per_batch, int64_t C, float *dt, void *dz, float *dgamma, float *dw,
+                               float *db, float *ws, void *stream) {
+    using namespace vah;
+    const char *fn = "vah_residual_layernorm_bwd";
+    clear_error();
+    if (batch < 0 || rows_per_batch < 0) return fail(VAH_E_SHAPE, "%s: bad dims", fn);
+    if (batch * rows_per_batch > 0 && (!z || !dz)) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if ((gamma != nullptr) != (dgamma != nullptr)) return fail(VAH_E_NULL, "%s: gamma and dgamma go together", fn);
+    if ((uintptr_t)gamma % 16 || ((uintptr_t)z | (uintptr_t)dz) % 8) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    return ln_bwd_launch(fn, t, gh, w, mean, rstd, gt, batch * rows_per_batch, C,
+                         ResidualIn{(const __bf16 *)z, gamma, sc, std::max<int64_t>(rows_per_batch, 1), nullptr}, dz, dt, dw,
+                         db, dgamma, ws, stream);
 }
 
 // out[c] = sum_r g[r][c] for a bf16 [rows, C] matrix, C % 8 == 0; ws: vah_reduce_ws_floats(C).
@@ -563,7 +664,7 @@ int vah_colsum_bf16(const void *g, int64_t rows, int64_t C, float *out, float *w
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)ctiles, (unsigned)parts), dim3(256), 0, st,
                        (const __bf16 *)g, rows, (int)C, (int)rpb, ws);
     hipLaunchKernelGGL(finalize_partials, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, st, ws, (int)parts,
-                       (int)C, out, (int)C, (float *)nullptr);
+                       (int)C, out, (int)C, (float *)nullptr, 1 << 30, (float *)nullptr);
     return check_launch(fn);
 }
 
@@ -608,7 +709,7 @@ int vah_scale_residual_bwd(const float *g, const void *z, const float *gamma, co
                        dgamma ? ws : nullptr);
     if (dgamma)
         hipLaunchKernelGGL(finalize_partials, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, st, ws,
-                           (int)nblocks, (int)C, dgamma, (int)C, (float *)nullptr);
+                           (int)nblocks, (int)C, dgamma, (int)C, (float *)nullptr, 1 << 30, (float *)nullptr);
     return check_launch(fn);
 }
 
@@ -680,7 +781,7 @@ int vah_dwconv3x3_tokens_wgrad_bf16(const void *x, const void *g, int64_t B, int
     hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((unsigned)nblocks), dim3(256), smem, st,
                        (const __bf16 *)x, (const __bf16 *)g, mp, N, (int)C, total_tok, ws);
     hipLaunchKernelGGL(finalize_partials, dim3((unsigned)((10 * C + 31) / 32)), dim3(256), 0, st, ws,
-                       (int)nblocks, (int)(10 * C), dw, (int)(9 * C), db);
+                       (int)nblocks, (int)(10 * C), dw, (int)(9 * C), db, 1 << 30, (float *)nullptr);
     return check_launch(fn);
 }
 

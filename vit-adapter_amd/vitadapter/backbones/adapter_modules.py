@@ -19,7 +19,7 @@ import torch.utils.checkpoint as cp
 from ops.modules import MSDeformAttn
 
 from .. import fused
-from .vit import DropPath
+from .vit import DropPath, run_blocks
 
 
 def get_reference_points(spatial_shapes, device):
@@ -126,11 +126,10 @@ class Extractor(nn.Module):
             query, qn = fused.layer_norm_keep(self.query_norm, query)
             attn = self.attn(qn, reference_points, fused.layer_norm(self.feat_norm, feat), spatial_shapes,
                              level_start_index, None)
-            query = fused.residual(query, attn)
             if self.with_cffn:
-                query, qn = fused.layer_norm_keep(self.ffn_norm, query)
-                query = fused.residual(query, self.ffn(qn, H, W), None, self.drop_path)
-            return query
+                query, qn = fused.residual_ln(query, attn, None, None, self.ffn_norm)
+                return fused.residual(query, self.ffn(qn, H, W), None, self.drop_path)
+            return fused.residual(query, attn)
 
         if self.with_cp and query.requires_grad:
             return cp.checkpoint(body, query, feat, use_reentrant=False)
@@ -194,8 +193,7 @@ class InteractionBlock(nn.Module):
     def forward(self, x, c, blocks, deform_inputs1, deform_inputs2, H, W):
         x = self.injector(query=x, reference_points=deform_inputs1[0], feat=c,
                           spatial_shapes=deform_inputs1[1], level_start_index=deform_inputs1[2])
-        for blk in blocks:
-            x = blk(x, H, W)
+        x = run_blocks(blocks, x, H, W)
         return x, self._extract(x, c, deform_inputs2, H, W)
 
 
@@ -207,8 +205,7 @@ class InteractionBlockWithCls(InteractionBlock):
         x = self.injector(query=x, reference_points=deform_inputs1[0], feat=c,
                           spatial_shapes=deform_inputs1[1], level_start_index=deform_inputs1[2])
         x = torch.cat((cls, x), dim=1)
-        for blk in blocks:
-            x = blk(x, H, W)
+        x = run_blocks(blocks, x, H, W)
         cls, x = x[:, :1], x[:, 1:]
         return x, self._extract(x, c, deform_inputs2, H, W), cls
 

@@ -219,23 +219,47 @@ class Block(nn.Module):
                                                bottleneck_channels=dim // 2, norm=LayerNorm,
                                                act_layer=act_layer)
 
-    def _body(self, x, H, W):
+    def _body(self, x, H, W, h=None, next_norm=None):
         # x + drop_path(gamma1 * attn(norm1(x))), x + drop_path(gamma2 * mlp(norm2(x)))
-        # (ref base/vit.py:301-306); fused.* fall back to exactly that expression off the bf16 path
-        x, h = fused.layer_norm_keep(self.norm1, x)
-        x = fused.residual(x, self.attn(h, H, W), self.gamma1 if self.layer_scale else None, self.drop_path)
-        x, h = fused.layer_norm_keep(self.norm2, x)
-        x = fused.residual(x, self.mlp(h), self.gamma2 if self.layer_scale else None, self.drop_path)
+        # (ref base/vit.py:301-306); fused.* fall back to exactly that expression off the bf16 path.
+        # ``h`` = norm1(x) when the caller already has it; with ``next_norm`` the result is
+        # (x, next_norm(x)): the residual update and the next LayerNorm run as one kernel.
+        g1, g2 = (self.gamma1, self.gamma2) if self.layer_scale else (None, None)
+        if h is None:
+            x, h = fused.layer_norm_keep(self.norm1, x)
+        x, h = fused.residual_ln(x, self.attn(h, H, W), g1, self.drop_path, self.norm2)
+        f = self.mlp(h)
+        if next_norm is not None and not self.use_residual:
+            return fused.residual_ln(x, f, g2, self.drop_path, next_norm)
+        x = fused.residual(x, f, g2, self.drop_path)
         if self.use_residual:
             B, N, C = x.shape
             y = self.residual(x.reshape(B, H, W, C).permute(0, 3, 1, 2))
             x = y.permute(0, 2, 3, 1).reshape(B, N, C)
-        return x
+        return x if next_norm is None else fused.layer_norm_keep(next_norm, x)
 
     def forward(self, x, H, W):
         if self.with_cp and x.requires_grad:
             return cp.checkpoint(self._body, x, H, W, use_reentrant=False)
         return self._body(x, H, W)
+
+    def forward_chain(self, x, H, W, h=None, next_norm=None):
+        """``forward`` for a run of blocks: takes norm1(x) from the previous block (``h``) and
+        returns (x, next_norm(x)) for the next one (``next_norm`` = its norm1), or x at the end."""
+        if self.with_cp and x.requires_grad:
+            x = cp.checkpoint(self._body, x, H, W, use_reentrant=False)
+            return x if next_norm is None else fused.layer_norm_keep(next_norm, x)
+        return self._body(x, H, W, h, next_norm)
+
+
+def run_blocks(blocks, x, H, W, h=None):
+    """x through ``blocks`` with each residual update fused to the LayerNorm that follows it."""
+    blocks = list(blocks)
+    for i, blk in enumerate(blocks):
+        nxt = blocks[i + 1].norm1 if i + 1 < len(blocks) else None
+        out = blk.forward_chain(x, H, W, h, nxt)
+        x, h = out if nxt is not None else (out, None)
+    return x
 
 
 class TIMMVisionTransformer(nn.Module):

@@ -12,7 +12,10 @@ import torch.nn.functional as F
 
 import _vah
 
-ENABLED = {'layer_norm': True, 'residual': True, 'dwconv': True, 'linear': True, 'bn_tail': True}
+ENABLED = {'layer_norm': True, 'residual': True, 'residual_ln': True, 'dwconv': True, 'linear': True, 'bn_tail': True}
+for _k in os.environ.get('VAH_FUSED_DISABLE', '').split(','):      # e.g. VAH_FUSED_DISABLE=residual_ln,bn_tail (A/B runs)
+    if _k:
+        ENABLED[_k.strip()] = False
 
 
 def _stream(t):
@@ -316,6 +319,85 @@ def residual(x, z, gamma=None, drop_path=None):
         return _ScaleResidual.apply(x, z, gamma, s)
     t = gamma * z if gamma is not None else z
     return x + (drop_path(t) if drop_path is not None else t)
+
+
+class _ResidualLN(torch.autograd.Function):
+    """(t, h) = (x + s * gamma * z, LayerNorm(t)) in one pass; the backward sums the gradient of t
+    along the residual stream and through the LayerNorm in-kernel and emits dz, dgamma with it."""
+
+    @staticmethod
+    def forward(ctx, x, z, gamma, s, weight, bias, eps):
+        B, C = x.shape[0], x.shape[-1]
+        rpb = x.numel() // (B * C)
+        x, z = x.contiguous(), z.contiguous()
+        t = torch.empty_like(x)
+        h = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        rows = B * rpb
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        gp = gamma.contiguous() if gamma is not None else None
+        w, b = weight.contiguous(), bias.contiguous()
+        with torch.cuda.device(x.device):
+            _vah.check(_vah.lib.vah_residual_layernorm_fwd(
+                x.data_ptr(), z.data_ptr(), gp.data_ptr() if gp is not None else None,
+                s.data_ptr() if s is not None else None, B, rpb, C, w.data_ptr(), b.data_ptr(), float(eps),
+                t.data_ptr(), h.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream(x)), 'residual_layernorm_fwd')
+        ctx.save_for_backward(t, z, gp, s, w, mean, rstd)
+        ctx.dims = (B, rpb, C)
+        ctx.set_materialize_grads(False)
+        return t, h
+
+    @staticmethod
+    def backward(ctx, gt, gh):
+        t, z, gp, s, w, mean, rstd = ctx.saved_tensors
+        B, rpb, C = ctx.dims
+        dev = t.device
+        if gt is not None:
+            gt = gt.contiguous().float()
+        if gh is None:                       # the normalised copy was not used: plain residual backward
+            if gt is None:
+                return (None,) * 7
+            dz = torch.empty_like(z)
+            dgamma = torch.empty(C, dtype=torch.float32, device=dev) if gp is not None else None
+            ws = _scratch(C, dev) if gp is not None else None
+            with torch.cuda.device(dev):
+                _vah.check(_vah.lib.vah_scale_residual_bwd(
+                    gt.data_ptr(), z.data_ptr(), gp.data_ptr() if gp is not None else None,
+                    s.data_ptr() if s is not None else None, B, rpb, C, dz.data_ptr(),
+                    dgamma.data_ptr() if dgamma is not None else None,
+                    ws.data_ptr() if ws is not None else None, _stream(gt)), 'scale_residual_bwd')
+            return gt, dz, dgamma, None, None, None, None
+        gh = gh.contiguous().to(torch.bfloat16)
+        dt = torch.empty_like(t)
+        dz = torch.empty_like(z)
+        grads = torch.empty(3, C, dtype=torch.float32, device=dev)
+        ws = _scratch(2 * C, dev)
+        with torch.cuda.device(dev):
+            _vah.check(_vah.lib.vah_residual_layernorm_bwd(
+                t.data_ptr(), gh.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                gt.data_ptr() if gt is not None else None, z.data_ptr(),
+                gp.data_ptr() if gp is not None else None, s.data_ptr() if s is not None else None, B, rpb, C,
+                dt.data_ptr(), dz.data_ptr(), grads[2].data_ptr() if gp is not None else None,
+                grads[0].data_ptr(), grads[1].data_ptr(), ws.data_ptr(), _stream(t)), 'residual_layernorm_bwd')
+        return dt, dz, grads[2] if gp is not None else None, None, grads[0], grads[1], None
+
+
+def _drop_path_scale(x, drop_path):
+    prob = float(getattr(drop_path, 'drop_prob', 0.) or 0.)
+    if prob > 0. and bool(getattr(drop_path, 'training', False)):
+        keep = 1.0 - prob
+        return x.new_empty((x.shape[0],)).bernoulli_(keep).div_(keep)
+    return None
+
+
+def residual_ln(x, z, gamma, drop_path, norm):
+    """``t = x + drop_path(gamma * z); return t, norm(t)`` - a residual update followed by the
+    LayerNorm of the next sub-block (base/vit.py:301-306), one pass over the rows each way."""
+    if (ENABLED['residual'] and ENABLED['residual_ln'] and _ln_fusable(norm, x) and z.dtype == torch.bfloat16
+            and x.shape == z.shape
+            and x.dim() >= 2 and (gamma is None or gamma.dtype == torch.float32) and x.shape[-1] <= 1024):
+        return _ResidualLN.apply(x, z, gamma, _drop_path_scale(x, drop_path), norm.weight, norm.bias, norm.eps)
+    return layer_norm_keep(norm, residual(x, z, gamma, drop_path))
 
 
 class _DWConvTokens(torch.autograd.Function):
