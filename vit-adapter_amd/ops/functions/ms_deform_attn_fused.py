@@ -47,7 +47,9 @@ def build_pull_schedule(reference_points, value_shapes, radius=None, tile=None, 
     dev = reference_points.device
     ref = reference_points.detach().float()[0]                  # (Lq, RL, 2)
     metas, cands, start = [], [], 0
-    margin = radius + 2.5
+    # a near sample lies within `radius` px of its reference point and touches the pixels
+    # floor(.) and floor(.) + 1: a query can reach a tile from at most radius + 1 px away
+    margin = radius + 1.0 + 0.05
     for l, (H, W) in enumerate(value_shapes):
         per_px = ref.shape[0] * n_points * 4.0 / float(H * W)       # expected bucket entries per pixel
         tile = tile_env if tile_env > 0 else (16 if per_px <= 12.0 else 8)
