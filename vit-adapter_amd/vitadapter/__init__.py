@@ -8,4 +8,7 @@ attention inside it runs on the hand-written gfx950 kernels of libvitadapter_hip
 """
 from .backbones import ViTAdapter, ViTAdapterDet, ViTAdapterSeg, register_backbones
 
-__all__ = ['ViTAdapter', 'ViTAdapterSeg', 'ViTAdapterDet', 'register_backbones']
+from .mmcv_attention import MultiScaleDeformableAttention, register_attention
+
+__all__ = ['ViTAdapter', 'ViTAdapterSeg', 'ViTAdapterDet', 'register_backbones',
+           'MultiScaleDeformableAttention', 'register_attention']
