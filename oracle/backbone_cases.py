@@ -78,3 +78,37 @@ BLOCK_CASES = {'blk_global': (False, 6, 7), 'blk_window': (True, 10, 17), 'blk_w
 def block_tokens(name):
     _, H, W = BLOCK_CASES[name]
     return seeded.randn('part/blk/' + name, (PART['batch'], H * W, PART['embed']), 12)
+
+
+# ---- BEiT adapter: fixed input size = img_size (the bias table is built for its grid)
+BEIT_CASES = {
+    'beit_seg_64': dict(cfg=dict(img_size=64, patch_size=16, embed_dim=64, depth=4, num_heads=2, mlp_ratio=4,
+                                 qkv_bias=True, use_abs_pos_emb=False, use_rel_pos_bias=True, init_values=1e-6,
+                                 drop_path_rate=0., conv_inplane=16, n_points=4, deform_num_heads=2,
+                                 cffn_ratio=0.25, deform_ratio=1.0, with_cp=False,
+                                 interaction_indexes=[[0, 0], [1, 1], [2, 2], [3, 3]]),
+                        hw=(64, 64), batch=2, modes=('eval', 'train')),
+    # two blocks per interaction (class token carried across blocks), deform_ratio 0.5
+    'beit_seg_96': dict(cfg=dict(img_size=96, patch_size=16, embed_dim=64, depth=4, num_heads=1, mlp_ratio=2,
+                                 qkv_bias=True, use_abs_pos_emb=False, use_rel_pos_bias=True, init_values=1e-6,
+                                 drop_path_rate=0., conv_inplane=16, n_points=4, deform_num_heads=1,
+                                 cffn_ratio=0.25, deform_ratio=0.5, with_cp=False,
+                                 interaction_indexes=[[0, 0], [1, 1], [2, 2], [3, 3]]),
+                        hw=(96, 96), batch=1, modes=('train',)),
+}
+
+
+def beit_input(name):
+    c = BEIT_CASES[name]
+    return seeded.randn('beit/%s/x' % name, (c['batch'], 3) + tuple(c['hw']), 13)
+
+
+def beit_gouts(name, shapes):
+    return [seeded.randn('beit/%s/g%d' % (name, k), s, 13) for k, s in enumerate(shapes)]
+
+
+def float_shapes(module):
+    """{key: shape} of the floating-point state_dict entries (+ num_batches_tracked): integer index
+    buffers such as relative_position_index are structural and keep the module's own values."""
+    return {k: tuple(v.shape) for k, v in module.state_dict().items()
+            if v.is_floating_point() or k.endswith('num_batches_tracked')}

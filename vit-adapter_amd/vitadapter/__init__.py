@@ -6,9 +6,11 @@ state_dict layout of the reference's two ``ViTAdapter`` classes
 /root/reference/detection/mmdet_custom/models/backbones/vit_adapter.py:19-132); the deformable
 attention inside it runs on the hand-written gfx950 kernels of libvitadapter_hip.so.
 """
-from .backbones import ViTAdapter, ViTAdapterDet, ViTAdapterSeg, register_backbones
+from .backbones import (BEiTAdapter, ViTAdapter, ViTAdapterDet, ViTAdapterSeg, register_backbones,
+                        register_beit_adapter)
 
 from .mmcv_attention import MultiScaleDeformableAttention, register_attention
 
-__all__ = ['ViTAdapter', 'ViTAdapterSeg', 'ViTAdapterDet', 'register_backbones',
+__all__ = ['ViTAdapter', 'ViTAdapterSeg', 'ViTAdapterDet', 'register_backbones', 'BEiTAdapter',
+           'register_beit_adapter',
            'MultiScaleDeformableAttention', 'register_attention']

@@ -1,0 +1,104 @@
+"""BEiTAdapter: the adapter around a BEiT trunk.
+
+Interface mirror of /root/reference/segmentation/mmseg_custom/models/backbones/beit_adapter.py:20-141
+(constructor arguments, parameter names, four-scale output); the class token travels through the
+ViT blocks and is split off again around every injector / extractor
+(``InteractionBlockWithCls``, adapter_modules.py:194-232).  BASELINE config 4's published model
+(seg/configs/ade20k/upernet_beit_adapter_large_640_160k_ade20k_ss.py:13-33).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from ops.modules import MSDeformAttn
+
+from .. import fused
+from .adapter_modules import InteractionBlockWithCls, SpatialPriorModule, deform_inputs
+from .beit import BEiT
+from .vit_adapter import ViTAdapter
+
+
+class BEiTAdapter(BEiT):
+    def __init__(self, pretrain_size=224, conv_inplane=64, n_points=4, deform_num_heads=6, init_values=0.,
+                 cffn_ratio=0.25, deform_ratio=1.0, with_cffn=True, interaction_indexes=None,
+                 add_vit_feature=True, with_cp=False, *args, **kwargs):
+        super().__init__(init_values=init_values, with_cp=with_cp, *args, **kwargs)
+        self.num_block = len(self.blocks)
+        self.pretrain_size = (pretrain_size, pretrain_size)
+        self.flags = [i for i in range(-1, self.num_block, self.num_block // 4)][1:]
+        self.interaction_indexes = interaction_indexes
+        self.add_vit_feature = add_vit_feature
+        self._pos_resize_cache = {}
+        embed_dim = self.embed_dim
+
+        self.level_embed = nn.Parameter(torch.zeros(3, embed_dim))
+        self.spm = SpatialPriorModule(inplanes=conv_inplane, embed_dim=embed_dim, with_cp=False)
+        last = len(interaction_indexes) - 1
+        self.interactions = nn.Sequential(*[
+            InteractionBlockWithCls(dim=embed_dim, num_heads=deform_num_heads, n_points=n_points,
+                                    init_values=init_values, drop_path=self.drop_path_rate,
+                                    norm_layer=self.norm_layer, with_cffn=with_cffn, cffn_ratio=cffn_ratio,
+                                    deform_ratio=deform_ratio, extra_extractor=(i == last), with_cp=with_cp)
+            for i in range(len(interaction_indexes))])
+        self.up = nn.ConvTranspose2d(embed_dim, embed_dim, 2, 2)
+        self.norm1 = nn.SyncBatchNorm(embed_dim)
+        self.norm2 = nn.SyncBatchNorm(embed_dim)
+        self.norm3 = nn.SyncBatchNorm(embed_dim)
+        self.norm4 = nn.SyncBatchNorm(embed_dim)
+
+        self.up.apply(self._init_weights)
+        self.spm.apply(self._init_weights)
+        self.interactions.apply(self._init_weights)
+        self.apply(self._init_deform_weights)
+        nn.init.normal_(self.level_embed)
+
+    # initialisation rules and pos-embed resize are the ViT adapter's (beit_adapter.py:61-90 repeats them)
+    _init_weights = ViTAdapter._init_weights
+    _bicubic_matrix = ViTAdapter._bicubic_matrix
+    _get_pos_embed = ViTAdapter._get_pos_embed
+    _add_level_embed = ViTAdapter._add_level_embed
+
+    def _init_deform_weights(self, m):
+        if isinstance(m, MSDeformAttn):
+            m._reset_parameters()
+
+    def forward(self, x):
+        fused.refresh_linear_copies(self)
+        deform_inputs1, deform_inputs2 = deform_inputs(x)
+
+        c1, c2, c3, c4 = self.spm(x)
+        c2, c3, c4 = self._add_level_embed(c2, c3, c4)
+        n2, n3 = c2.size(1), c3.size(1)
+        c = torch.cat([c2, c3, c4], dim=1)
+
+        x, H, W = self.patch_embed(x)
+        bs, n, dim = x.shape
+        cls = self.cls_token.expand(bs, -1, -1)
+        if self.pos_embed is not None:
+            x = x + self._get_pos_embed(self.pos_embed[:, 1:] if self.pos_embed.shape[1] == n + 1
+                                        else self.pos_embed, H, W)
+        x = self.pos_drop(x)
+
+        outs = []
+        for i, layer in enumerate(self.interactions):
+            lo, hi = self.interaction_indexes[i][0], self.interaction_indexes[i][-1]
+            x, c, cls = layer(x, c, cls, self.blocks[lo:hi + 1], deform_inputs1, deform_inputs2, H, W)
+            outs.append(x.transpose(1, 2).reshape(bs, dim, H, W).contiguous())
+
+        c2 = c[:, :n2].transpose(1, 2).reshape(bs, dim, H * 2, W * 2).contiguous()
+        c3 = c[:, n2:n2 + n3].transpose(1, 2).reshape(bs, dim, H, W).contiguous()
+        c4 = c[:, n2 + n3:].transpose(1, 2).reshape(bs, dim, H // 2, W // 2).contiguous()
+        if self.add_vit_feature:
+            x1, x2, x3, x4 = outs
+            c4 = c4 + fused.halve(x4)
+            return [fused.bn_tail(self.norm1, self.up(c2), c1, x1, 4), fused.bn_tail(self.norm2, c2, None, x2, 2),
+                    fused.bn_tail(self.norm3, c3, None, x3, 1), self.norm4(c4)]
+        c1 = self.up(c2) + c1
+        return [self.norm1(c1), self.norm2(c2), self.norm3(c3), self.norm4(c4)]
+
+
+def register_beit_adapter(registry=None, name='BEiTAdapter', force=True):
+    """Register into mmseg's BACKBONES under the reference's name."""
+    if registry is None:
+        from mmseg.models.builder import BACKBONES as registry
+    registry.register_module(name=name, force=force, module=BEiTAdapter)
+    return BEiTAdapter
