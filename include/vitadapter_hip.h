@@ -149,8 +149,14 @@ int vah_msda_backward_win_f32(const float *value, const int64_t *shapes, const i
  * both axes are then accumulated per tile in LDS buckets and flushed with one atomic per pixel row;
  * the others are scattered with per-sample atomics as without a schedule.  cap_entries = capacity of
  * the per-workgroup record store (10 bytes each, <= 150 KiB, even, < 65536); overflow falls back to
- * atomics, as does the whole pass when N*Lq*M >= 2^24.  The
- * result is the same gradient (fp32 summation order aside) for any valid schedule.
+ * atomics, as does the whole pass when N*Lq*M >= 2^24.
+ * cap_entries = 0 selects the DENSE form (bf16 values only): per tile and chunk of 128 candidates the
+ * in-tile (attention x bilinear) weights are added into a dense (64 pixels x 128 queries) matrix in
+ * LDS and multiplied with the staged grad_out rows on the matrix cores (weights as bf16 hi + lo,
+ * fp32 accumulation) - no records, no sort, no per-record row gather; tiles should be 8 x 8
+ * (larger ones are processed in 64-pixel slabs).  The
+ * result is the same gradient (fp32 summation order and, in the dense form, ~2^-17 relative
+ * rounding of the weights aside) for any valid schedule.
  * ------------------------------------------------------------------------------------ */
 int vah_msda_fused_supported(int64_t D, int64_t L, int64_t P);
 int vah_msda_fused_forward(const void *value, int value_dtype, const int64_t *shapes, const int64_t *lsi,

@@ -15,6 +15,8 @@
 //
 // Restrictions of this path: D == 32, (L, P) in {(1,4), (3,4), (4,4)}, reference points shared by
 // the batch with last dim 2 (the adapter's).  Everything else uses the unfused Function.
+#include <type_traits>
+
 #include "msda_common.h"
 
 namespace vah {
@@ -515,6 +517,152 @@ __global__ __launch_bounds__(kGvThreads) void msda_fused_bwd_gv(
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// grad_value of the near samples on the matrix cores ("dense pull", bf16 grad_out rows).
+//
+// For a tile of <= 64 pixels and a chunk of 64 candidate queries the gradient is the product
+//     dV[pixel, channel] = sum_q  W[pixel, q] * G[q, channel],
+// W[pixel, q] = sum over the query's samples and corners that land on the pixel of
+// (attention weight x bilinear weight): a small DENSE matrix built in LDS by the sampling pass
+// itself (sparse LDS adds: ~3 per candidate), G = the candidates' grad_out rows staged
+// transposed.  Two waves then run v_mfma_f32_32x32x16_bf16 over it (W split into bf16 hi + lo so
+// the weights keep ~16 mantissa bits; G is bf16 as stored).  No hit records, no counting sort and
+// no per-record gather of 64-byte grad_out rows through L2 - the two things the sort form spends its
+// time on (profiles/r01_msda_pull_backward.txt).  The MFMA work is ~50x the useful flops of
+// the sparse form and still only ~14 GFLOP per call.
+// Tiles with more than 64 pixels are processed in slabs of 64 (correct, slower): the host builds
+// 8x8 tiles for this kernel.
+// ---------------------------------------------------------------------------------------
+constexpr int kDenseKC = 64;                   // candidates per chunk = 256 threads / 4 points
+constexpr int kDenseWS = kDenseKC + 4;         // W row stride (floats)
+constexpr int kDenseGS = kDenseKC + 8;         // G^T row stride (bf16): 144 B, 16-byte aligned rows
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 dbf16x8;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float df32x16;
+
+// Thread t of a chunk owns candidate t >> 2 and its sampling point t & 3 (P == 4), and the 8-channel
+// quarter t & 3 of the candidate's grad_out row: everything it needs hangs off ONE candidate id, so
+// a chunk costs one dependent global-load latency (the id of the NEXT chunk is fetched a chunk
+// ahead), and at 22 KB of LDS seven workgroups per CU overlap their chunks.
+template <typename PT, int L, int P>
+__global__ __launch_bounds__(256) void msda_fused_bwd_gv_mfma(
+    const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi, const PT *__restrict__ off,
+    const PT *__restrict__ logit, const float *__restrict__ ref, int ref_levels,
+    const __bf16 *__restrict__ grad_out, const int *__restrict__ tile_meta, const int *__restrict__ cand,
+    int ntiles, int64_t S, int M, int64_t Lq, float near_radius, float *__restrict__ grad_value) {
+    static_assert(P == 4, "one thread per (candidate, point): 4 points");
+    constexpr int LP = L * P;
+    __shared__ __attribute__((aligned(16))) float s_w[64 * kDenseWS];
+    __shared__ __attribute__((aligned(16))) __bf16 s_gt[kD * kDenseGS];
+
+    // tile-major order: the host sorts the tiles by candidate count, so the long ones start first
+    const int64_t b = blockIdx.x;
+    const int NM = (int)(gridDim.x / ntiles);
+    const int tile = (int)(b / NM);
+    const int m = (int)(b % NM) % M;
+    const int64_t n = (b % NM) / M;
+    const TileMeta tm = reinterpret_cast<const TileMeta *>(tile_meta)[tile];
+    const int l = tm.level;
+    const Level lv = read_level(shapes, lsi, l, S);
+    const int npx = tm.ny * tm.nx;
+    if (!lv.valid || npx <= 0 || tm.cand_count <= 0) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, r = lane & 31, h = lane >> 5;
+    const int ci = tid >> 2, p = tid & 3;
+    float *gv_level = grad_value + (n * S + lv.start) * (int64_t)M * kD + (int64_t)m * kD;
+
+    for (int px0 = 0; px0 < npx; px0 += 64) {
+        df32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        int q_next = ci < tm.cand_count ? cand[tm.cand_start + ci] : -1;
+        for (int c0 = 0; c0 < tm.cand_count; c0 += kDenseKC) {
+            int q = q_next;
+            if (q < 0 || q >= Lq) q = -1;
+            const int nxt = c0 + kDenseKC + ci;
+            q_next = nxt < tm.cand_count ? cand[tm.cand_start + nxt] : -1;
+            // ---- issue every load of this thread's (candidate, point) at once
+            const int64_t row = (n * Lq + max(q, 0)) * M + m;
+            const dbf16x8 gq = *reinterpret_cast<const dbf16x8 *>(grad_out + row * kD + p * 8);
+            const float2 o = load2(off + (row * LP + l * P + p) * 2);
+            const float2 rp = *reinterpret_cast<const float2 *>(ref + ((int64_t)max(q, 0) * ref_levels + (ref_levels > 1 ? l : 0)) * 2);
+            float pr[LP];                          // raw logits now, softmax only if a corner lands in the tile
+#pragma unroll
+            for (int s = 0; s < LP; ++s) pr[s] = (float)logit[row * LP + s];
+            // ---- zero W, stage the grad_out quarter-row transposed
+            for (int i = tid; i < 64 * kDenseWS / 4; i += 256)
+                reinterpret_cast<float4 *>(s_w)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s_gt[(p * 8 + e) * kDenseGS + ci] = q >= 0 ? gq[e] : (__bf16)0.f;
+            __syncthreads();
+            // ---- the point's in-tile corners -> W[pixel][candidate]; same location arithmetic as make_tap
+            if (q >= 0 && fabsf(o.x) <= near_radius && fabsf(o.y) <= near_radius) {      // else far: kernel A
+                const float lx = rp.x + o.x / (float)lv.W, ly = rp.y + o.y / (float)lv.H;
+                const float h_im = ly * (float)lv.H - 0.5f, w_im = lx * (float)lv.W - 0.5f;
+                if (h_im > -1.f && w_im > -1.f && h_im < (float)lv.H && w_im < (float)lv.W) {
+                    const float hf = floorf(h_im), wf = floorf(w_im);
+                    const int ry0 = (int)hf - tm.y0, rx0 = (int)wf - tm.x0;       // the tile lies inside the map
+                    const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+                    const bool y_in[2] = {ry0 >= 0 && ry0 < tm.ny, ry0 + 1 >= 0 && ry0 + 1 < tm.ny};
+                    const bool x_in[2] = {rx0 >= 0 && rx0 < tm.nx, rx0 + 1 >= 0 && rx0 + 1 < tm.nx};
+                    if ((y_in[0] || y_in[1]) && (x_in[0] || x_in[1])) {
+                        float mx = -INFINITY, sum = 0.f, mine = 0.f;
+#pragma unroll
+                        for (int s = 0; s < LP; ++s) mx = fmaxf(mx, pr[s]);
+#pragma unroll
+                        for (int s = 0; s < LP; ++s) {
+                            const float e = __expf(pr[s] - mx);
+                            sum += e;
+                            mine = (s == l * P + p) ? e : mine;
+                        }
+                        const float a = mine * (1.f / sum);
+                        const float cw[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            if (!(y_in[k >> 1] && x_in[k & 1])) continue;
+                            const int pp = (ry0 + (k >> 1)) * tm.nx + rx0 + (k & 1) - px0;
+                            if (pp < 0 || pp >= 64) continue;
+                            atomicAdd(&s_w[pp * kDenseWS + ci], cw[k] * a);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- dV[64 px, 32 ch] += W[64, KC] G[KC, 32]: wave w owns pixels 32(w&1) .. +31 and the
+            // candidates 32(w>>1) .. +31 of the chunk (partial sums of the two halves meet in the atomics)
+            {
+                const float *wrow = s_w + ((wv & 1) * 32 + r) * kDenseWS + 8 * h + 32 * (wv >> 1);
+                const __bf16 *grow = s_gt + r * kDenseGS + 8 * h + 32 * (wv >> 1);
+#pragma unroll
+                for (int ks = 0; ks < kDenseKC / 32; ++ks) {
+                    const float4 w0 = *reinterpret_cast<const float4 *>(wrow + 16 * ks);
+                    const float4 w1 = *reinterpret_cast<const float4 *>(wrow + 16 * ks + 4);
+                    const float wf[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+                    dbf16x8 ahi, alo;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        ahi[e] = (__bf16)wf[e];
+                        alo[e] = (__bf16)(wf[e] - (float)ahi[e]);
+                    }
+                    const dbf16x8 bg = *reinterpret_cast<const dbf16x8 *>(grow + 16 * ks);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bg, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bg, acc, 0, 0, 0);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- one 128-byte atomic per pixel row and wave: lane = channel r, registers = pixel rows
+        {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int pp = px0 + (wv & 1) * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+                if (pp < npx) {
+                    const int y = tm.y0 + pp / tm.nx, x = tm.x0 + pp % tm.nx;
+                    atomicAdd(gv_level + ((int64_t)y * lv.W + x) * (int64_t)M * kD + r, acc[i]);
+                }
+            }
+        }
+    }
+}
+
 struct FusedArgs {
     const void *value, *off, *logit, *grad_out;
     const int64_t *shapes, *lsi;
@@ -567,6 +715,17 @@ int launch_bwd(const FusedArgs &a) {
     // pull pass for the near samples
     const int64_t gblocks = a.N * a.M * a.ntiles;
     if (gblocks >= ((int64_t)1 << 31)) return fail(VAH_E_SHAPE, "msda fused backward: tile grid too large");
+    if (a.cap == 0) {                            // dense pull on the matrix cores (bf16 grad_out rows only)
+        if constexpr (std::is_same<VT, __bf16>::value) {
+            hipLaunchKernelGGL((msda_fused_bwd_gv_mfma<PT, L, P>), dim3((unsigned)gblocks), dim3(256), 0, a.st, a.shapes,
+                               a.lsi, (const PT *)a.off, (const PT *)a.logit, a.ref, a.ref_levels,
+                               (const __bf16 *)a.grad_out, a.tile_meta, a.cand, (int)a.ntiles, a.S, (int)a.M, a.Lq,
+                               a.near_radius, a.grad_value);
+            return check_launch("msda fused backward (dense pull) launch");
+        } else {
+            return fail(VAH_E_UNSUPPORTED, "msda fused backward: the dense pull (cap_entries = 0) needs bf16 values");
+        }
+    }
     const size_t smem = (size_t)a.cap * 10;      // records (8 B) + order (2 B)
     static bool attr_set = false;
     if (!attr_set) {
@@ -652,10 +811,12 @@ int vah_msda_fused_backward(const void *value, int value_dtype, const int64_t *s
     using namespace vah;
     clear_error();
     const char *fn = "vah_msda_fused_backward";
-    if (tile_meta && (!cand || ntiles < 1 || near_radius < 0.f || cap_entries < 64 || cap_entries * 10 > 150 * 1024 ||
-                      cap_entries > 65535 || (cap_entries & 1)))
+    if (tile_meta && (!cand || ntiles < 1 || near_radius < 0.f ||
+                      (cap_entries != 0 && (cap_entries < 64 || cap_entries * 10 > 150 * 1024 || cap_entries > 65535 ||
+                                            (cap_entries & 1)))))
         return fail(VAH_E_SHAPE, "%s: bad pull schedule", fn);
-    if (tile_meta && N * Lq * M >= (1 << 24)) tile_meta = nullptr;     // packed row index has 24 bits: plain path
+    if (tile_meta && cap_entries != 0 && N * Lq * M >= (1 << 24)) tile_meta = nullptr;     // packed row index has 24 bits: plain path
+    if (tile_meta && Lq >= ((int64_t)1 << 31)) tile_meta = nullptr;
     if (int rc = check_common(fn, N, S, M, D, L, Lq, P, ref_levels)) return rc;
     if (N * Lq * M == 0) return VAH_OK;
     if (!value || !shapes || !lsi || !offsets || !logits || !ref || !grad_out || !grad_value || !d_offsets || !d_logits)

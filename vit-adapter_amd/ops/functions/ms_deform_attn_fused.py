@@ -38,12 +38,20 @@ class PullSchedule:
 _PULL_CACHE = {}
 
 
-def build_pull_schedule(reference_points, value_shapes, radius=None, tile=None, n_points=4):
+def dense_pull(value_dtype):
+    """The matrix-core form of the pull pass (bf16 grad_out rows; VAH_MSDA_PULL_MODE=sort|dense)."""
+    return value_dtype == torch.bfloat16 and os.environ.get('VAH_MSDA_PULL_MODE', 'dense') == 'dense'
+
+
+def build_pull_schedule(reference_points, value_shapes, radius=None, tile=None, n_points=4, dense=False):
     """reference_points (1, Lq, 1|L, 2) on the GPU, value_shapes [(H, W)] host ints.
     Tile edge per level: 16 px where the level is sparsely sampled (few bucket entries per pixel),
     else 8 px, so that a tile's bucket store (~ pixels x entries per pixel) fits one workgroup."""
     radius = float(os.environ.get('VAH_MSDA_PULL_RADIUS', 5.0)) if radius is None else float(radius)
     tile_env = int(os.environ.get('VAH_MSDA_PULL_TILE', 0)) if tile is None else int(tile)
+    if dense and tile_env <= 0:
+        tile_env = 8                       # the dense kernel multiplies 64-pixel slabs
+    split = max(64, int(os.environ.get('VAH_MSDA_PULL_SPLIT', 2048)))
     dev = reference_points.device
     ref = reference_points.detach().float()[0]                  # (Lq, RL, 2)
     metas, cands, start = [], [], 0
@@ -67,27 +75,37 @@ def build_pull_schedule(reference_points, value_shapes, radius=None, tile=None, 
                 sel = idx_y[(pxs >= x0 - margin) & (pxs <= x0 + nx - 1 + margin)]
                 if sel.numel() == 0:
                     continue
-                metas.append([l, y0, x0, ny, nx, start, int(sel.numel()), 0])
-                cands.append(sel.to(torch.int32))
-                start += int(sel.numel())
+                # the dense kernel walks a candidate list 64 at a time: long lists are cut into several
+                # entries of the same tile (their partial sums meet in the atomics) so that the
+                # workgroups are many and even
+                step = split if dense else int(sel.numel())
+                for s0 in range(0, int(sel.numel()), step):
+                    part = sel[s0:s0 + step]
+                    metas.append([l, y0, x0, ny, nx, 0, int(part.numel()), 0])
+                    cands.append(part.to(torch.int32))
     if not metas:
         return None
+    order = sorted(range(len(metas)), key=lambda i: -metas[i][6])       # longest lists first
+    metas, cands = [metas[i] for i in order], [cands[i] for i in order]
+    for mt, cd in zip(metas, cands):
+        mt[5] = start
+        start += int(cd.numel())
     meta = torch.tensor(metas, dtype=torch.int32, device=dev)
     cand = torch.cat(cands).contiguous()
     cap = int(os.environ.get('VAH_MSDA_PULL_CAP', 7168))      # 70 KB of LDS: two workgroups per CU
-    return PullSchedule(meta, cand, len(metas), radius, cap)
+    return PullSchedule(meta, cand, len(metas), radius, 0 if dense else cap)      # cap 0 selects the dense kernel
 
 
-def pull_schedule_for(reference_points, spatial_shapes):
+def pull_schedule_for(reference_points, spatial_shapes, dense=False):
     """Cached per reference-point tensor (one host read of the (L, 2) shapes on the first call)."""
     if os.environ.get('VAH_MSDA_PULL', '1') == '0':
         return None
     key = (reference_points.data_ptr(), tuple(reference_points.shape), reference_points._version,
-           spatial_shapes.data_ptr(), str(reference_points.device))
+           spatial_shapes.data_ptr(), str(reference_points.device), bool(dense))
     hit = _PULL_CACHE.get(key)
     if hit is None:
         shapes = [tuple(int(v) for v in hw) for hw in spatial_shapes.tolist()]
-        sched = build_pull_schedule(reference_points, shapes)
+        sched = build_pull_schedule(reference_points, shapes, dense=dense)
         if len(_PULL_CACHE) > 64:
             _PULL_CACHE.clear()
         _PULL_CACHE[key] = (sched, reference_points, spatial_shapes)     # keep the keys' tensors alive
@@ -114,7 +132,7 @@ class MSDeformAttnFusedFunction(Function):
                 out.data_ptr(), torch.cuda.current_stream(value.device).cuda_stream)
         _vah.check(rc, 'vah_msda_fused_forward')
         ctx.save_for_backward(value, spatial_shapes, level_start_index, offsets, logits, ref)
-        ctx.pull = pull_schedule_for(reference_points, spatial_shapes)
+        ctx.pull = pull_schedule_for(reference_points, spatial_shapes, dense_pull(value.dtype))
         return out
 
     @staticmethod
