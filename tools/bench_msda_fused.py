@@ -23,7 +23,7 @@ def main():
         L, S = len(shapes), sum(h * w for h, w in shapes)
         g = torch.Generator(device='cuda').manual_seed(0)
         value = torch.randn(N, S, M, D, device='cuda', generator=g).to(dt).requires_grad_(True)
-        off = (cases.ring_offsets(M, L, P).cuda()[None, None] + torch.randn(N, Lq, M, L, P, 2, device='cuda', generator=g)).to(dt).requires_grad_(True)
+        off = (cases.ring_offsets(M, L, P).cuda()[None, None] + float(os.environ.get("VAH_BENCH_NOISE", "1")) * torch.randn(N, Lq, M, L, P, 2, device="cuda", generator=g)).to(dt).requires_grad_(True)
         logit = torch.randn(N, Lq, M, L * P, device='cuda', generator=g).to(dt).requires_grad_(True)
         ref = cases.reference_grid(qshapes).cuda()
         hw = torch.as_tensor(shapes, dtype=torch.long, device='cuda')

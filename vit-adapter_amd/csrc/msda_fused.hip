@@ -79,6 +79,11 @@ constexpr int kD = 32;
 // ---------------------------------------------------------------------------------------
 // forward: 8 lanes x 4 channels per row, query-major work order (see msda.hip)
 // ---------------------------------------------------------------------------------------
+struct TapF {           // one sampling tap as the 8 channel lanes of a row read it back from LDS
+    int row[4];         // token index of the corner inside its level (0 for an invalid corner)
+    float w[4];         // bilinear weight of the corner (0 for an invalid corner)
+};
+
 template <typename VT, typename PT, int L, int P>
 __global__ __launch_bounds__(kBlock) void msda_fused_fwd(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
@@ -87,10 +92,37 @@ __global__ __launch_bounds__(kBlock) void msda_fused_fwd(
     VT *__restrict__ out) {
     constexpr int LP = L * P;
     constexpr int ROWS = kBlock / 8;
+    __shared__ __attribute__((aligned(16))) TapF s_tap[ROWS * LP];
     const int64_t blk = xcd_chunked_block(nblocks);
     if (blk >= nblocks) return;
-    const int sub = threadIdx.x & 7;
-    const int64_t work = blk * ROWS + (threadIdx.x >> 3);
+    // phase 1: every tap of the block's rows once (not once per channel lane), see msda_fused_bwd_vec4
+    for (int i = threadIdx.x; i < ROWS * LP; i += kBlock) {
+        const int rl = i / LP, sidx = i - rl * LP, l = sidx / P;
+        const int64_t w = blk * ROWS + rl;
+        TapF tl;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tl.row[k] = 0;
+            tl.w[k] = 0.f;
+        }
+        const Level lv = read_level(shapes, lsi, l, S);
+        if (w < total_rows && lv.valid) {
+            const int64_t q = w % Lq;
+            const int64_t rw = (w / Lq / M * Lq + q) * M + (w / Lq) % M;
+            const float2 o = load2(off + (rw * LP + sidx) * 2);
+            const float2 rp = *reinterpret_cast<const float2 *>(ref + (q * ref_levels + (ref_levels > 1 ? l : 0)) * 2);
+            const Tap<float> t = make_tap<float>(rp.x + o.x / (float)lv.W, rp.y + o.y / (float)lv.H, lv.H, lv.W);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                tl.row[k] = t.row[k];
+                tl.w[k] = t.ok[k] ? t.cw[k] : 0.f;
+            }
+        }
+        s_tap[i] = tl;
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int64_t work = blk * ROWS + rl;
     if (work >= total_rows) return;
     const int64_t q = work % Lq;
     const int m = (int)((work / Lq) % M);
@@ -101,21 +133,16 @@ __global__ __launch_bounds__(kBlock) void msda_fused_fwd(
 
     float p[LP];
     row_softmax<PT, LP>(logit + row * LP, p);
-    const PT *op = off + row * LP * 2;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         const Level lv = read_level(shapes, lsi, l, S);
         if (!lv.valid) continue;
-        const float2 rp = *reinterpret_cast<const float2 *>(ref + (q * ref_levels + (ref_levels > 1 ? l : 0)) * 2);
         const VT *vl = vhead + lv.start * stride;
-        Tap<float> t[P];
+        TapF t[P];
         float4 v[P][4];
 #pragma unroll
-        for (int u = 0; u < P; ++u) {
-            const float2 o = load2(op + 2 * (l * P + u));
-            t[u] = make_tap<float>(rp.x + o.x / (float)lv.W, rp.y + o.y / (float)lv.H, lv.H, lv.W);
-        }
+        for (int u = 0; u < P; ++u) t[u] = s_tap[rl * LP + l * P + u];
 #pragma unroll
         for (int u = 0; u < P; ++u)
 #pragma unroll
@@ -125,12 +152,11 @@ __global__ __launch_bounds__(kBlock) void msda_fused_fwd(
             float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const float c = t[u].cw[k];
-                const bool ok = t[u].ok[k];
-                s4.x += c * (ok ? v[u][k].x : 0.f);
-                s4.y += c * (ok ? v[u][k].y : 0.f);
-                s4.z += c * (ok ? v[u][k].z : 0.f);
-                s4.w += c * (ok ? v[u][k].w : 0.f);
+                const float c = t[u].w[k];
+                s4.x += c * v[u][k].x;
+                s4.y += c * v[u][k].y;
+                s4.z += c * v[u][k].z;
+                s4.w += c * v[u][k].w;
             }
             const float a = p[l * P + u];
             acc.x += s4.x * a;
@@ -236,6 +262,14 @@ __device__ __forceinline__ float sum8(float x) {
     return x;                       // every lane of the 8-lane group holds the sum
 }
 
+// One sampling tap as the 8 channel lanes of a row read it back from LDS.
+struct TapL {
+    int row[4];        // token index of the corner inside its level, -1 = invalid corner
+    float lh, lw;
+    int far;           // 1: outside near_radius (its grad_value goes through atomics here)
+    int pad;
+};
+
 template <typename VT, typename PT, int L, int P>
 __global__ __launch_bounds__(kBlock) void msda_fused_bwd_vec4(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
@@ -245,11 +279,40 @@ __global__ __launch_bounds__(kBlock) void msda_fused_bwd_vec4(
     PT *__restrict__ d_logit) {
     constexpr int LP = L * P;
     constexpr int ROWS = kBlock / 8;
+    __shared__ __attribute__((aligned(16))) TapL s_tap[ROWS * LP];
     const int64_t blk = xcd_chunked_block(nblocks);
     if (blk >= nblocks) return;
-    const int sub = threadIdx.x & 7;
-    const int64_t work = blk * ROWS + (threadIdx.x >> 3);
-    if (work >= total_rows) return;          // whole 8-lane groups leave together
+    // ---- phase 1: every sampling tap of the block's rows is computed ONCE (the 8 channel lanes of a
+    // row used to redo the divisions / floors / index arithmetic of all L*P samples each: the
+    // kernel ran 80 us of its 143 us with the value gather switched off)
+    for (int i = threadIdx.x; i < ROWS * LP; i += kBlock) {
+        const int rl = i / LP, sidx = i - rl * LP, l = sidx / P;
+        const int64_t w = blk * ROWS + rl;
+        TapL tl;
+        tl.row[0] = tl.row[1] = tl.row[2] = tl.row[3] = -1;
+        tl.lh = tl.lw = 0.f;
+        tl.far = 0;
+        tl.pad = 0;
+        if (w < total_rows) {
+            const int64_t q = w % Lq;
+            const int64_t rw = (w / Lq / M * Lq + q) * M + (w / Lq) % M;
+            const Level lv = read_level(shapes, lsi, l, S);
+            const float2 o = load2(off + (rw * LP + sidx) * 2);
+            const float2 rp = *reinterpret_cast<const float2 *>(ref + (q * ref_levels + (ref_levels > 1 ? l : 0)) * 2);
+            const Tap<float> t = make_tap<float>(lv.valid ? rp.x + o.x / (float)lv.W : -8.f,
+                                                 lv.valid ? rp.y + o.y / (float)lv.H : -8.f, max(lv.H, 1), max(lv.W, 1));
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tl.row[k] = (lv.valid && t.ok[k]) ? t.row[k] : -1;
+            tl.lh = t.lh;
+            tl.lw = t.lw;
+            tl.far = (lv.valid && !(fabsf(o.x) <= near_radius && fabsf(o.y) <= near_radius)) ? 1 : 0;
+        }
+        s_tap[i] = tl;
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int64_t work = blk * ROWS + rl;
+    if (work >= total_rows) return;          // whole 8-lane groups leave together (after the barrier)
     const int64_t q = work % Lq;
     const int m = (int)((work / Lq) % M);
     const int64_t n = work / Lq / M;
@@ -259,41 +322,35 @@ __global__ __launch_bounds__(kBlock) void msda_fused_bwd_vec4(
 
     float p[LP], ga[LP], gx[LP], gy[LP];
     row_softmax<PT, LP>(logit + row * LP, p);
-    const PT *op = off + row * LP * 2;
     const float4 g = load4(grad_out + row * kD + sub * 4);
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         const Level lv = read_level(shapes, lsi, l, S);
-        const float2 rp = *reinterpret_cast<const float2 *>(ref + (q * ref_levels + (ref_levels > 1 ? l : 0)) * 2);
         const VT *vl = value + head_off + lv.start * stride;
         float *gvl = grad_value + head_off + lv.start * stride;
-        Tap<float> t[P];
+        TapL t[P];
         float4 v[P][4];
-        bool scatter[P];
 #pragma unroll
-        for (int u = 0; u < P; ++u) {
-            const float2 o = load2(op + 2 * (l * P + u));
-            scatter[u] = !(fabsf(o.x) <= near_radius && fabsf(o.y) <= near_radius);
-            t[u] = make_tap<float>(lv.valid ? rp.x + o.x / (float)lv.W : -8.f,
-                                   lv.valid ? rp.y + o.y / (float)lv.H : -8.f, max(lv.H, 1), max(lv.W, 1));
-        }
+        for (int u = 0; u < P; ++u) t[u] = s_tap[rl * LP + l * P + u];
 #pragma unroll
         for (int u = 0; u < P; ++u)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 v[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (lv.valid && t[u].ok[k]) v[u][k] = load4(vl + (int64_t)t[u].row[k] * stride);
+                if (t[u].row[k] >= 0) v[u][k] = load4(vl + (int64_t)t[u].row[k] * stride);
             }
 #pragma unroll
         for (int u = 0; u < P; ++u) {
             const int s = l * P + u;
             const float a = p[s];
-            if (scatter[u] && lv.valid) {
+            const float lh = t[u].lh, lw = t[u].lw, hh = 1.f - lh, hw = 1.f - lw;
+            const float cw[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
+            if (t[u].far) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (t[u].ok[k]) {
+                    if (t[u].row[k] >= 0) {
                         float *d = gvl + (int64_t)t[u].row[k] * stride;
-                        const float w = t[u].cw[k] * a;
+                        const float w = cw[k] * a;
                         atomicAdd(d + 0, w * g.x);
                         atomicAdd(d + 1, w * g.y);
                         atomicAdd(d + 2, w * g.z);
@@ -303,9 +360,9 @@ __global__ __launch_bounds__(kBlock) void msda_fused_bwd_vec4(
             // per-lane partial dot products over its 4 channels
             auto dot4 = [&](const float4 &x) { return g.x * x.x + g.y * x.y + g.z * x.z + g.w * x.w; };
             const float d0 = dot4(v[u][0]), d1 = dot4(v[u][1]), d2 = dot4(v[u][2]), d3 = dot4(v[u][3]);
-            const float val = t[u].cw[0] * d0 + t[u].cw[1] * d1 + t[u].cw[2] * d2 + t[u].cw[3] * d3;
-            const float gh = t[u].hw * (d2 - d0) + t[u].lw * (d3 - d1);
-            const float gw = t[u].hh * (d1 - d0) + t[u].lh * (d3 - d2);
+            const float val = cw[0] * d0 + cw[1] * d1 + cw[2] * d2 + cw[3] * d3;
+            const float gh = hw * (d2 - d0) + lw * (d3 - d1);
+            const float gw = hh * (d1 - d0) + lh * (d3 - d2);
             ga[s] = sum8(val);
             gx[s] = sum8(gw * a);
             gy[s] = sum8(gh * a);
