@@ -39,6 +39,15 @@ using namespace vah::msda;
 // instead of consecutive heads of one query.  Neighbouring queries sample overlapping corner rows,
 // so the 8 rows a wave instruction asks for collapse to fewer distinct cache lines in the TA and
 // neighbouring waves re-hit L1: less L2 -> L1 traffic, which is what bounds this kernel.
+struct TapF {           // one sampling tap as the channel lanes of a row read it back from LDS
+    int row[4];         // token index of the corner inside its level (0 for an invalid corner)
+    float w[4];         // attention weight x bilinear weight of the corner (0 for an invalid corner)
+};
+
+// Phase 1: every sampling tap of the workgroup's rows is computed ONCE by one thread and handed to
+// the LANES channel lanes of its row through LDS (dynamic, ROWS * L * P entries of 32 bytes); before,
+// each channel lane redid the floor / index arithmetic of all L*P taps of its row, and that
+// redundant VALU work - not the gather - was half of the kernel's time on the adapter shapes.
 template <int LANES, int PU, bool QMAJOR>
 __global__ __launch_bounds__(kBlock) void msda_fwd_vec4(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
@@ -47,27 +56,56 @@ __global__ __launch_bounds__(kBlock) void msda_fwd_vec4(
     int64_t total_rows, int64_t nblocks, float *__restrict__ out) {
     constexpr int D = 4 * LANES;
     constexpr int ROWS = kBlock / LANES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    TapF *s_tap = reinterpret_cast<TapF *>(s_raw);
     const int64_t blk = xcd_chunked_block(nblocks);
     if (blk >= nblocks) return;
-    const int sub = threadIdx.x % LANES;
-    const int64_t work = blk * ROWS + threadIdx.x / LANES;
+    const int LP = L * P;
+    auto row_of = [&](int64_t work, int &m, int64_t &n) -> int64_t {
+        if (QMAJOR) {
+            const int64_t q = work % Lq;
+            m = (int)((work / Lq) % M);
+            n = work / Lq / M;
+            return (n * Lq + q) * M + m;
+        }
+        m = (int)(work % M);
+        n = work / M / Lq;
+        return work;
+    };
+    for (int i = threadIdx.x; i < ROWS * LP; i += kBlock) {
+        const int rl = i / LP, sidx = i - rl * LP, l = sidx / P;
+        const int64_t work = blk * ROWS + rl;
+        TapF tl;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            tl.row[k] = 0;
+            tl.w[k] = 0.f;
+        }
+        const Level lv = read_level(shapes, lsi, l, S);
+        if (work < total_rows && lv.valid) {
+            int m;
+            int64_t n;
+            const int64_t row = row_of(work, m, n);
+            const float2 xy = *reinterpret_cast<const float2 *>(loc + (row * LP + sidx) * 2);
+            const float a = attn[row * LP + sidx];
+            const Tap<float> t = make_tap<float>(xy.x, xy.y, lv.H, lv.W);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                tl.row[k] = t.row[k];
+                tl.w[k] = t.ok[k] ? t.cw[k] * a : 0.f;
+            }
+        }
+        s_tap[i] = tl;
+    }
+    __syncthreads();
+    const int sub = threadIdx.x % LANES, rl = threadIdx.x / LANES;
+    const int64_t work = blk * ROWS + rl;
     if (work >= total_rows) return;
     int m;
-    int64_t n, row;
-    if (QMAJOR) {
-        const int64_t q = work % Lq;
-        m = (int)((work / Lq) % M);
-        n = work / Lq / M;
-        row = (n * Lq + q) * M + m;
-    } else {
-        row = work;
-        m = (int)(row % M);
-        n = row / M / Lq;
-    }
+    int64_t n;
+    const int64_t row = row_of(work, m, n);
     const int64_t stride = (int64_t)M * D;                       // floats per token
     const float *vhead = value + n * S * stride + m * D + sub * 4;
-    const float *lp = loc + row * (int64_t)(L * P) * 2;
-    const float *ap = attn + row * (int64_t)(L * P);
 
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int l = 0; l < L; ++l) {
@@ -75,38 +113,25 @@ __global__ __launch_bounds__(kBlock) void msda_fwd_vec4(
         if (!lv.valid) continue;
         const float *vl = vhead + lv.start * stride;
         for (int p0 = 0; p0 < P; p0 += PU) {
-            Tap<float> t[PU];
-            float a[PU];
+            TapF t[PU];
             float4 v[PU][4];
 #pragma unroll
-            for (int u = 0; u < PU; ++u) {
-                const int s = l * P + p0 + u;
-                const float2 xy = *reinterpret_cast<const float2 *>(lp + 2 * s);
-                a[u] = ap[s];
-                t[u] = make_tap<float>(xy.x, xy.y, lv.H, lv.W);
-            }
+            for (int u = 0; u < PU; ++u) t[u] = s_tap[rl * LP + l * P + p0 + u];
 #pragma unroll
             for (int u = 0; u < PU; ++u)
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     v[u][k] = *reinterpret_cast<const float4 *>(vl + (int64_t)t[u].row[k] * stride);
 #pragma unroll
-            for (int u = 0; u < PU; ++u) {
-                float4 s4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int u = 0; u < PU; ++u)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const float c = t[u].cw[k];
-                    const bool ok = t[u].ok[k];
-                    s4.x += c * (ok ? v[u][k].x : 0.f);
-                    s4.y += c * (ok ? v[u][k].y : 0.f);
-                    s4.z += c * (ok ? v[u][k].z : 0.f);
-                    s4.w += c * (ok ? v[u][k].w : 0.f);
+                    const float c = t[u].w[k];
+                    acc.x += c * v[u][k].x;
+                    acc.y += c * v[u][k].y;
+                    acc.z += c * v[u][k].z;
+                    acc.w += c * v[u][k].w;
                 }
-                acc.x += s4.x * a[u];
-                acc.y += s4.y * a[u];
-                acc.z += s4.z * a[u];
-                acc.w += s4.w * a[u];
-            }
         }
     }
     *reinterpret_cast<float4 *>(out + row * D + sub * 4) = acc;
@@ -357,6 +382,7 @@ int launch_fwd_vec4(const Dims &d, const float *value, const int64_t *shapes, co
     const int64_t nblocks = (d.rows + ROWS - 1) / ROWS;
     const int64_t grid = (nblocks + 7) / 8 * 8;
     if (grid >= ((int64_t)1 << 31)) return fail(VAH_E_SHAPE, "msda forward: grid too large");
+    const size_t smem = (size_t)ROWS * d.L * d.P * sizeof(TapF);         // the workgroup's tap table
     static const bool qmajor = [] {
         const char *e = getenv("VAH_MSDA_FWD_QMAJOR");
         return e ? atoi(e) != 0 : true;
@@ -364,11 +390,11 @@ int launch_fwd_vec4(const Dims &d, const float *value, const int64_t *shapes, co
 #define VAH_FWD(PU)                                                                               \
     do {                                                                                          \
         if (qmajor)                                                                               \
-            hipLaunchKernelGGL((msda_fwd_vec4<LANES, PU, true>), dim3((unsigned)grid), dim3(kBlock), 0, \
+            hipLaunchKernelGGL((msda_fwd_vec4<LANES, PU, true>), dim3((unsigned)grid), dim3(kBlock), smem, \
                                st, value, shapes, lsi, loc, attn, d.S, (int)d.M, (int)d.L, d.Lq,   \
                                (int)d.P, d.rows, nblocks, out);                                    \
         else                                                                                      \
-            hipLaunchKernelGGL((msda_fwd_vec4<LANES, PU, false>), dim3((unsigned)grid), dim3(kBlock), 0, \
+            hipLaunchKernelGGL((msda_fwd_vec4<LANES, PU, false>), dim3((unsigned)grid), dim3(kBlock), smem, \
                                st, value, shapes, lsi, loc, attn, d.S, (int)d.M, (int)d.L, d.Lq,   \
                                (int)d.P, d.rows, nblocks, out);                                    \
     } while (0)
@@ -412,7 +438,9 @@ int forward_impl(const char *fn, const T *value, const int64_t *shapes, const in
     hipStream_t st = (hipStream_t)stream;
     LaunchScope scope(sizeof(T) == 4 ? "msda_fwd_f32" : "msda_fwd_f64", fwd_bytes(d, sizeof(T)), st);
     if constexpr (sizeof(T) == 4) {
-        const bool vec_ok = aligned(value, 16) && aligned(out, 16) && aligned(loc, 8);
+        // the vector kernels keep one 32-byte tap per (row, level, point) of the workgroup in LDS
+        const bool vec_ok = aligned(value, 16) && aligned(out, 16) && aligned(loc, 8) &&
+                            (kBlock * 4 / D) * L * P * 32 <= 48 * 1024;
         if (vec_ok && D == 32) return launch_fwd_vec4<8>(d, value, shapes, lsi, loc, attn, out, st);
         if (vec_ok && D == 16) return launch_fwd_vec4<4>(d, value, shapes, lsi, loc, attn, out, st);
         if (vec_ok && D == 64) return launch_fwd_vec4<16>(d, value, shapes, lsi, loc, attn, out, st);
