@@ -269,3 +269,63 @@ def test_fused_backward_pull_schedule_equals_atomics(monkeypatch, L, shapes, qsh
         for a, b, nm in zip(res[tag], base, ('out', 'grad_value', 'd_off', 'd_logit')):
             err = (a - b).abs().max().item()
             assert err <= 1e-4 * max(1.0, b.abs().max().item()), (tag, nm, err)
+
+
+@pytest.mark.parametrize('L,shapes,qshapes,scale', [
+    (3, [(32, 32), (16, 16), (8, 8)], [(16, 16)], 1.0),
+    (1, [(16, 24)], [(32, 48), (16, 24), (8, 12)], 1.0),
+    (1, [(24, 16)], [(48, 32), (24, 16), (12, 8)], 3.0),        # many far samples
+])
+def test_fused_backward_dense_pull_equals_sort_and_atomics(monkeypatch, L, shapes, qshapes, scale):
+    """bf16 values: the matrix-core ("dense") pull pass against the sort form and per-sample atomics on
+    the same bf16 operands - 8x8 tiles, 16x16 tiles (64-pixel slabs), a 5-pixel tile grid with a
+    small radius.  All three accumulate in fp32 and round grad_value to bf16 once, so they agree to
+    bf16 rounding; d_offsets / d_logits come from the same kernel and must be identical."""
+    from ops.functions import MSDeformAttnFusedFunction
+    from ops.functions import ms_deform_attn_fused as mf
+    torch.manual_seed(12)
+    N, M, D, P = 2, 4, 32, 4
+    S, Lq = sum(h * w for h, w in shapes), sum(h * w for h, w in qshapes)
+    bf = torch.bfloat16
+    value = torch.randn(N, S, M, D, device='cuda').to(bf)
+    off = ((cases.ring_offsets(M, L, P).cuda()[None, None] + torch.randn(N, Lq, M, L, P, 2, device='cuda')) * scale).to(bf)
+    logit = torch.randn(N, Lq, M, L * P, device='cuda').to(bf)
+    ref = cases.reference_grid(qshapes).cuda()
+    hw = torch.as_tensor(shapes, dtype=torch.long, device='cuda')
+    lsi = cases.level_start_index(shapes).cuda()
+    gout = torch.randn(N, Lq, M * D, device='cuda').to(bf)
+    keys = ('VAH_MSDA_PULL', 'VAH_MSDA_PULL_MODE', 'VAH_MSDA_PULL_RADIUS', 'VAH_MSDA_PULL_TILE')
+    res = {}
+    for tag, env in (('atomics', {'VAH_MSDA_PULL': '0'}), ('sort', {'VAH_MSDA_PULL_MODE': 'sort'}),
+                     ('dense', {'VAH_MSDA_PULL_MODE': 'dense'}),
+                     ('dense_t16', {'VAH_MSDA_PULL_MODE': 'dense', 'VAH_MSDA_PULL_TILE': '16'}),
+                     ('dense_r2', {'VAH_MSDA_PULL_MODE': 'dense', 'VAH_MSDA_PULL_RADIUS': '2.0', 'VAH_MSDA_PULL_TILE': '5'})):
+        for k in keys:
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        mf._PULL_CACHE.clear()
+        v, o, lg = [t.clone().requires_grad_(True) for t in (value, off, logit)]
+        out = MSDeformAttnFusedFunction.apply(v, hw, lsi, o, lg, ref)
+        out.backward(gout)
+        if tag.startswith('dense'):
+            assert mf.pull_schedule_for(ref, hw, True).cap == 0
+        res[tag] = (out.detach().float(), v.grad.float(), o.grad.float(), lg.grad.float())
+    mf._PULL_CACHE.clear()
+    base = res['atomics']
+    for tag in ('sort', 'dense', 'dense_t16', 'dense_r2'):
+        assert torch.equal(res[tag][0], base[0])
+        for i, nm in ((2, 'd_off'), (3, 'd_logit')):      # other kernel (8 lanes x 4 channels) than the atomics path
+            err = (res[tag][i] - base[i]).abs().max().item()
+            assert err <= 1.2e-2 * max(1.0, base[i].abs().max().item()), (tag, nm, err)
+        if tag != 'dense_r2':                              # same far / near split: the very same kernel and inputs
+            assert torch.equal(res[tag][2], res['sort'][2]) and torch.equal(res[tag][3], res['sort'][3])
+        err = (res[tag][1] - base[1]).abs().max().item()
+        assert err <= 1.2e-2 * max(1.0, base[1].abs().max().item()), (tag, err)
+    # the dense form is not a bf16-quality shortcut: against the fp32 evaluation of the same operands
+    v32 = value.float().requires_grad_(True)
+    monkeypatch.setenv('VAH_MSDA_PULL', '0')
+    MSDeformAttnFusedFunction.apply(v32, hw, lsi, off.float(), logit.float(), ref).backward(gout.float())
+    for tag in ('atomics', 'dense'):
+        err = (res[tag][1] - v32.grad).abs().max().item()
+        assert err <= 1.2e-2 * max(1.0, v32.grad.abs().max().item()), (tag, err)
