@@ -1,0 +1,86 @@
+"""GPU, world_size 2 over gloo with both ranks on the one card: the real product path (HIP kernels,
+bf16 autocast with every fused operator, SyncBatchNorm in TRAIN mode incl. the fused output tail)
+under DDP gives the gradients of one process running the full batch with plain BatchNorm.
+
+Complements tests/test_data_parallel_cpu.py (host wiring on the CPU).  RCCL itself cannot be
+exercised with one GPU; the collective calls are the same torch.distributed calls."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _build():
+    for p in (ROOT, os.path.join(ROOT, 'vit-adapter_amd')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from oracle import backbone_cases as bc
+    from oracle import seeded
+    from vitadapter.backbones import ViTAdapter
+    case = bc.FULL_CASES['det_win_96x128']
+    model = ViTAdapter(**case['cfg'])
+    shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+    model.load_state_dict(seeded.seeded_state_dict(shapes, 5))
+    x = seeded.randn('dpgpu/x', (4, 3, 96, 128), 3)
+    return model.cuda().train(), x.cuda()
+
+
+def _loss(model, x):
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        feats = model(x)
+    return sum(f.float().mean() for f in feats)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world),
+                      MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    model, x = _build()
+    from vitadapter import data_parallel as dp
+    dp.init_from_env(backend='gloo')
+    net = dp.wrap(model, torch.device('cuda', 0))
+    assert isinstance(net, torch.nn.parallel.DistributedDataParallel)
+    _loss(net, dp.shard(x, rank, world)).backward()
+    grads = {k: p.grad.float().cpu() for k, p in model.named_parameters() if p.grad is not None}
+    stats = {k: v.float().cpu() for k, v in model.state_dict().items() if 'running_' in k}
+    torch.save((grads, stats), os.path.join(out_dir, 'rank%d.pt' % rank))
+    dp.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_rank_ddp_on_gpu_matches_single_process(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    from vitadapter.data_parallel import revert_sync_batchnorm
+    model, x = _build()
+    model = revert_sync_batchnorm(model).cuda().train()          # one process, whole batch, plain BN
+    _loss(model, x).backward()
+    (g0, s0), (g1, _) = (torch.load(os.path.join(tmp_path, 'rank%d.pt' % r), weights_only=True) for r in (0, 1))
+    checked = worst = 0
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        assert torch.equal(g0[k], g1[k]), k                      # all-reduced: identical on both ranks
+        ref = p.grad.float().cpu()
+        # bf16 kernels + a different summation order (two half batches): bf16-level agreement
+        err = float((g0[k] - ref).abs().max()) / max(1e-3, float(ref.abs().max()))
+        worst = max(worst, err)
+        assert err <= 6e-2, (k, err)
+        checked += 1
+    assert checked > 150
+    for k, v in model.state_dict().items():
+        if 'running_' in k:                                      # SyncBN statistics span both ranks' images
+            assert float((s0[k] - v.float().cpu()).abs().max()) <= 2e-2 * max(1.0, float(v.abs().max())), k
