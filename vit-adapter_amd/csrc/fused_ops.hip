@@ -144,8 +144,8 @@ __global__ __launch_bounds__(256) void finalize_partials(const float *__restrict
 
 // LayerNorm backward: a wave walks rows (grid stride), keeps per-column dw/db partials in
 // registers; the 4 waves of a workgroup are summed through LDS into one partial row [dw | db].
-template <int kMaxVec>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ x,
+template <int kMaxVec, int kWaves>
+__global__ __launch_bounds__(64 * kWaves) void ln_bwd_kernel(const float *__restrict__ x,
                                                      const __bf16 *__restrict__ g,
                                                      const float *__restrict__ w,
                                                      const float *__restrict__ mean,
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ x
                                                      ResidualIn res, __bf16 *__restrict__ dz,
                                                      float *__restrict__ dx, float *__restrict__ part) {
     // partial row: [dw | db] or, with a fused residual update in front, [dw | db | dgamma]
-    extern __shared__ __attribute__((aligned(16))) float s_red[];      // [4][ncol * C]
+    extern __shared__ __attribute__((aligned(16))) float s_red[];      // [kWaves][ncol * C]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nvec = C >> 2;
     const int ncol = res.z ? 3 : 2;
@@ -173,8 +173,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ x
     // Two rows per wave in flight: with <= 512 workgroups a wave walks only a few rows, and one row's
     // loads -> two wave reductions -> stores is a serial chain (measured 45 us at 1.9 TB/s per call
     // with one row in flight).
-    const int64_t stride = (int64_t)gridDim.x * 4;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < rows; row += 2 * stride) {
+    const int64_t stride = (int64_t)gridDim.x * kWaves;
+    for (int64_t row = (int64_t)blockIdx.x * kWaves + wv; row < rows; row += 2 * stride) {
         int64_t rws[2] = {row, row + stride};
         const int nrow = rws[1] < rows ? 2 : 1;
         float4 xv[2][kMaxVec], rv[2][kMaxVec];
@@ -266,7 +266,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float *__restrict__ x
     __syncthreads();
     const int K = ncol * C;
     float *pr = part + (int64_t)blockIdx.x * K;
-    for (int k = threadIdx.x; k < K; k += 256) pr[k] = s_red[k] + s_red[K + k] + s_red[2 * K + k] + s_red[3 * K + k];
+    for (int k = threadIdx.x; k < K; k += 64 * kWaves) {
+        float t = 0.f;
+#pragma unroll
+        for (int u = 0; u < kWaves; ++u) t += s_red[u * K + k];
+        pr[k] = t;
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -595,18 +600,33 @@ static int ln_bwd_launch(const char *fn, const float *x, const void *g, const fl
     if (!x || !g || !w || !mean || !rstd || !dx) return fail(VAH_E_NULL, "%s: null pointer", fn);
     if (((uintptr_t)x | (uintptr_t)w | (uintptr_t)dx | (uintptr_t)gres) % 16 || (uintptr_t)g % 8) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
     const int ncol = res.z ? 3 : 2;
-    int64_t nblocks = (rows + 3) / 4;
+    // 8 waves per workgroup when their LDS reduction buffer leaves room for two workgroups per CU:
+    // the partial-row cap bounds the grid at 512 workgroups, and with 4 waves each that is 2 waves per
+    // SIMD - too few to cover the latency of this kernel's load -> reduce -> store chain
+    const int waves = (size_t)8 * ncol * C * sizeof(float) <= 76 * 1024 ? 8 : 4;
+    int64_t nblocks = (rows + waves - 1) / waves;
     nblocks = std::min<int64_t>(nblocks, kMaxParts * 2 / ncol);          // the scratch holds kMaxParts * 2C floats
-    const size_t smem = (size_t)4 * ncol * C * sizeof(float);
+    const size_t smem = (size_t)waves * ncol * C * sizeof(float);
     LaunchScope scope(res.z ? "residual_layernorm_bwd" : "layernorm_bwd", rows * C * (res.z ? 18 : 10), st);
-#define VAH_LN_BWD(NV)                                                                          \
-    hipLaunchKernelGGL(ln_bwd_kernel<NV>, dim3((unsigned)nblocks), dim3(256), smem, st, x,      \
-                       (const __bf16 *)g, w, mean, rstd, gres, rows, (int)C, res, (__bf16 *)dz, dx, ws)
-    if (smem > 64 * 1024) return fail(VAH_E_SHAPE, "%s: C too large for the fused form", fn);
-    if (C <= 256) VAH_LN_BWD(1);
-    else if (C <= 512) VAH_LN_BWD(2);
-    else if (C <= 1024) VAH_LN_BWD(4);
-    else VAH_LN_BWD(8);
+    if (smem > 150 * 1024) return fail(VAH_E_SHAPE, "%s: C too large for the fused form", fn);
+#define VAH_LN_BWD(NV, WV)                                                                       \
+    do {                                                                                         \
+        if (smem > 64 * 1024)                                                                    \
+            (void)hipFuncSetAttribute((const void *)ln_bwd_kernel<NV, WV>,                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);    \
+        hipLaunchKernelGGL((ln_bwd_kernel<NV, WV>), dim3((unsigned)nblocks), dim3(64 * WV), smem, st, x, \
+                           (const __bf16 *)g, w, mean, rstd, gres, rows, (int)C, res, (__bf16 *)dz, dx, ws); \
+    } while (0)
+#define VAH_LN_BWD_W(NV)        \
+    do {                        \
+        if (waves == 8) VAH_LN_BWD(NV, 8); \
+        else VAH_LN_BWD(NV, 4); \
+    } while (0)
+    if (C <= 256) VAH_LN_BWD_W(1);
+    else if (C <= 512) VAH_LN_BWD_W(2);
+    else if (C <= 1024) VAH_LN_BWD_W(4);
+    else VAH_LN_BWD_W(8);
+#undef VAH_LN_BWD_W
 #undef VAH_LN_BWD
     // partial row = [dw | db | dgamma]
     hipLaunchKernelGGL(finalize_partials, dim3((unsigned)((ncol * C + 31) / 32)), dim3(256), 0, st, ws,
