@@ -61,6 +61,23 @@ def main():
             'torch add f32 (ref)': (12, lambda s: torch.add(s['x'], s['gres'], out=s['y'])),
             'torch copy f32->bf16 (ref)': (6, lambda s: s['h'].copy_(s['x'])),
         }
+        if rows % 42 == 0:                                  # ConvFFN token tensor: 21 n tokens per image
+            Cd, Hd = C // 4, int((rows // B // 21) ** 0.5) * 2
+            if 21 * (Hd // 2) ** 2 * B == rows:
+                xs = [torch.randn(rows, Cd, device=d).bfloat16() for _ in range(8)]
+                ys = [torch.empty(rows, Cd, device=d, dtype=torch.bfloat16) for _ in range(8)]
+                wd, bd = torch.randn(Cd, 9, device=d), torch.randn(Cd, device=d)
+                dwg = torch.empty(Cd * 10, device=d)
+                wsd = torch.empty(L.vah_reduce_ws_floats(10 * Cd), device=d)
+                for s_, (xx, yy) in zip(sets * 8, zip(xs, ys)):
+                    pass
+                dsets = [dict(x=a, y=b_) for a, b_ in zip(xs, ys)]
+                for name, bpe, fn in (
+                        ('dwconv fwd (C/4)', 4, lambda s: L.vah_dwconv3x3_tokens_bf16(p(s['x']), p(wd), p(bd), B, Hd, Hd, Cd, 0, p(s['y']), st)),
+                        ('dwconv dgrad (C/4)', 4, lambda s: L.vah_dwconv3x3_tokens_bf16(p(s['x']), p(wd), None, B, Hd, Hd, Cd, 1, p(s['y']), st)),
+                        ('dwconv wgrad (C/4)', 4, lambda s: L.vah_dwconv3x3_tokens_wgrad_bf16(p(s['x']), p(s['y']), B, Hd, Hd, Cd, p(dwg), p(dwg[Cd * 9:]), p(wsd), st))):
+                    us = timeit(fn, dsets)
+                    print('  %-28s %7.1f us  %6.2f TB/s' % (name, us, rows * Cd * bpe / us / 1e6))
         print('rows %d C %d, %d buffer sets' % (rows, C, nsets))
         for name, (bpe, fn) in ops.items():
             us = timeit(fn, sets)

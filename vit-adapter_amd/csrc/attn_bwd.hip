@@ -22,30 +22,43 @@ namespace vah {
 namespace attn {
 namespace {
 
-// delta[z,h,i] = sum_d dO[row,h,d] * O[row,h,d]   (0 for padded tokens)
-__global__ __launch_bounds__(256) void attn_delta_kernel(const __bf16 *__restrict__ o,
-                                                         const __bf16 *__restrict__ d_o, int64_t ld_out,
-                                                         RowMap rm, int N, int H, int64_t total,
-                                                         float *__restrict__ delta) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;       // over (z, h, n), n fastest
-    if (i >= total) return;
-    const int n = (int)(i % N);
-    const int h = (int)((i / N) % H);
-    const int z = (int)(i / N / H);
-    const int64_t gr = grow(rm, z, n, N);
-    float acc = 0.f;
-    if (gr >= 0) {
-        const __bf16 *po = o + gr * ld_out + (int64_t)h * kHD;
-        const __bf16 *pd = d_o + gr * ld_out + (int64_t)h * kHD;
+// Backward prologue in ONE launch: K^T, Q^T, dO^T (64-token tiles) and, from the dO tile it already
+// holds, delta = rowsum(dO * O).  Four small launches before (3 transposes + delta): on the 196-token
+// windows they cost as much as the dQ kernel itself.
+__global__ __launch_bounds__(256) void attn_bwd_prologue_kernel(
+    const __bf16 *__restrict__ q, const __bf16 *__restrict__ k, int64_t ld, const __bf16 *__restrict__ o,
+    const __bf16 *__restrict__ d_o, int64_t ld_out, RowMap rm, int N, int Np, int H, __bf16 *__restrict__ kt,
+    __bf16 *__restrict__ qt, __bf16 *__restrict__ dot, float *__restrict__ delta) {
+    __shared__ __attribute__((aligned(16))) __bf16 tile[64 * kPadRow];
+    const int ntile = Np / 64;
+    const int which = blockIdx.x / ntile, n0 = (blockIdx.x - which * ntile) * 64;
+    const int h = blockIdx.y, b = blockIdx.z;
+    if (which == 0) {
+        transpose_tile_to_dn(k, ld, rm, N, Np, H, kt, n0, h, b, tile);
+    } else if (which == 1) {
+        transpose_tile_to_dn(q, ld, rm, N, Np, H, qt, n0, h, b, tile);
+    } else {
+        transpose_tile_to_dn(d_o, ld_out, rm, N, Np, H, dot, n0, h, b, tile);
+        // delta of the tile's 64 tokens: 4 threads per token, 16 channels each, dO from the LDS tile
+        const int row = threadIdx.x >> 2, part = threadIdx.x & 3;
+        const int n = n0 + row;
+        float acc = 0.f;
+        const int64_t gr = n < N ? grow(rm, b, n, N) : -1;
+        if (gr >= 0) {
+            const __bf16 *po = o + gr * ld_out + (int64_t)h * kHD + part * 16;
+            const __bf16 *pd = tile + row * kPadRow + part * 16;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const bf16x8 a = *reinterpret_cast<const bf16x8 *>(po + 8 * c);
-            const bf16x8 g = *reinterpret_cast<const bf16x8 *>(pd + 8 * c);
+            for (int c = 0; c < 2; ++c) {
+                const bf16x8 a = *reinterpret_cast<const bf16x8 *>(po + 8 * c);
+                const bf16x8 g = *reinterpret_cast<const bf16x8 *>(pd + 8 * c);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)g[j];
+                for (int j = 0; j < 8; ++j) acc += (float)a[j] * (float)g[j];
+            }
         }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        if (part == 0 && n < N) delta[((int64_t)b * H + h) * N + n] = acc;
     }
-    delta[i] = acc;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -358,12 +371,9 @@ static int attn_bwd_impl(const char *fn, const void *q, const void *k, const voi
     const dim3 tg(Np / 64, (unsigned)H, (unsigned)B);
     {
         LaunchScope scope("attn_transpose_bf16", 3 * 2 * B * H * N * kHD * 2, st);
-        hipLaunchKernelGGL(transpose_to_dn, tg, dim3(256), 0, st, (const __bf16 *)k, ld, rm, (int)N, Np, (int)H, kt);
-        hipLaunchKernelGGL(transpose_to_dn, tg, dim3(256), 0, st, (const __bf16 *)q, ld, rm, (int)N, Np, (int)H, qt);
-        hipLaunchKernelGGL(transpose_to_dn, tg, dim3(256), 0, st, (const __bf16 *)dout, ld_out, rm, (int)N, Np, (int)H, dot);
-        const int64_t total = B * H * N;
-        hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st,
-                           (const __bf16 *)out, (const __bf16 *)dout, ld_out, rm, (int)N, (int)H, total, delta);
+        hipLaunchKernelGGL(attn_bwd_prologue_kernel, dim3(3 * tg.x, tg.y, tg.z), dim3(256), 0, st, (const __bf16 *)q,
+                           (const __bf16 *)k, ld, (const __bf16 *)out, (const __bf16 *)dout, ld_out, rm, (int)N, Np,
+                           (int)H, kt, qt, dot, delta);
         if (int rc = check_launch(fn)) return rc;
     }
     const float scale_log2 = scale * 1.4426950408889634f;

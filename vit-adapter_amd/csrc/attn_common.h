@@ -83,11 +83,10 @@ int make_rowmap(const char *fn, int64_t win, int64_t B, int64_t gh, int64_t gw, 
                 RowMap *rm);
 
 // (rows, heads, 64) strided -> (Z, heads, 64, Np) dense, zero padded beyond N / outside the image.
-static __global__ __launch_bounds__(256) void transpose_to_dn(const __bf16 *__restrict__ src, int64_t ld,
-                                                              RowMap rm, int N, int Np, int H,
-                                                              __bf16 *__restrict__ dst) {
-    __shared__ __attribute__((aligned(16))) __bf16 tile[64 * kPadRow];
-    const int n0 = blockIdx.x * 64, h = blockIdx.y, b = blockIdx.z;
+// One 64-token tile; `tile` is 64 * kPadRow bf16 of LDS, left holding the (token, d) tile.
+__device__ __forceinline__ void transpose_tile_to_dn(const __bf16 *__restrict__ src, int64_t ld, const RowMap &rm,
+                                                     int N, int Np, int H, __bf16 *__restrict__ dst, int n0, int h,
+                                                     int b, __bf16 *tile) {
     const __bf16 *s = src + (int64_t)h * kHD;
     for (int c = threadIdx.x; c < 512; c += 256) {
         const int row = c >> 3, col = (c & 7) * 8;
@@ -107,6 +106,13 @@ static __global__ __launch_bounds__(256) void transpose_to_dn(const __bf16 *__re
         for (int j = 0; j < 8; ++j) v[j] = tile[(k0 + j) * kPadRow + drow];
         *reinterpret_cast<bf16x8 *>(d + (int64_t)drow * Np + k0) = v;
     }
+}
+
+static __global__ __launch_bounds__(256) void transpose_to_dn(const __bf16 *__restrict__ src, int64_t ld,
+                                                              RowMap rm, int N, int Np, int H,
+                                                              __bf16 *__restrict__ dst) {
+    __shared__ __attribute__((aligned(16))) __bf16 tile[64 * kPadRow];
+    transpose_tile_to_dn(src, ld, rm, N, Np, H, dst, blockIdx.x * 64, blockIdx.y, blockIdx.z, tile);
 }
 
 }  // namespace attn

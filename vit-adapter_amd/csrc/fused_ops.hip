@@ -434,8 +434,8 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const __bf16 *__restrict__ 
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE == 0 && bias) b4 = *reinterpret_cast<const float4 *>(bias + 4 * cv);
     for (int64_t tokg = (int64_t)blockIdx.x * slots + slot; tokg < total_tok; tokg += (int64_t)gridDim.x * slots) {
-        const int tok = (int)(tokg % N);
-        const int64_t b = tokg / N;
+        const int64_t b = (int)tokg / N;              // total_tok < 2^31 (checked by the host): 32-bit divisions
+        const int tok = (int)tokg - (int)b * N;
         const int m = map_of(mp, tok);
         const int H = mp.h[m], W = mp.w[m], t0 = mp.t[m];
         const int py = (tok - t0) / W, px = (tok - t0) - py * W;
@@ -751,14 +751,15 @@ int vah_dwconv3x3_tokens_bf16(const void *x, const float *w, const float *bias, 
     mp.h[2] = (int)(H / 2), mp.w[2] = (int)(W / 2);
     const int N = (int)(21 * n);
     const int64_t total_tok = B * N;
+    if (total_tok >= ((int64_t)1 << 31)) return fail(VAH_E_SHAPE, "%s: too many tokens", fn);
     const int slots = 256 / (int)(C / 4);
     hipStream_t st = (hipStream_t)stream;
     LaunchScope scope(mode == 0 ? "dwconv_tokens_fwd" : "dwconv_tokens_dgrad", total_tok * C * 4, st);
     if (mode == 0)
-        hipLaunchKernelGGL(dwconv_kernel<0>, dim3(grid_for(total_tok, slots * 4)), dim3(256), 0, st,
+        hipLaunchKernelGGL(dwconv_kernel<0>, dim3(grid_for(total_tok, slots * 2)), dim3(256), 0, st,
                            (const __bf16 *)x, w, bias, mp, N, (int)C, total_tok, (__bf16 *)y);
     else
-        hipLaunchKernelGGL(dwconv_kernel<1>, dim3(grid_for(total_tok, slots * 4)), dim3(256), 0, st,
+        hipLaunchKernelGGL(dwconv_kernel<1>, dim3(grid_for(total_tok, slots * 2)), dim3(256), 0, st,
                            (const __bf16 *)x, w, bias, mp, N, (int)C, total_tok, (__bf16 *)y);
     return check_launch(fn);
 }
