@@ -274,14 +274,22 @@ int vah_bn_tail_stats(const void *a, int a_bf16, const void *b, int b_bf16, cons
                       int64_t N, int64_t C, int64_t H, int64_t W, float *sums, float *ws, void *stream);
 int vah_bn_tail_apply(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale,
                       int64_t N, int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd,
-                      const float *gamma, const float *beta, float *y, void *stream);
+                      const float *gamma, const float *beta, int relu, void *y, int y_bf16, void *stream);
 int vah_bn_tail_bwd_stats(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale,
                           int64_t N, int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd,
-                          const float *dy, float *sums, float *ws, void *stream);
+                          const float *gamma, const float *beta, int relu, const void *dy, int dy_bf16,
+                          float *sums, float *ws, void *stream);
 int vah_bn_tail_bwd_apply(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale,
                           int64_t N, int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd,
-                          const float *gamma, const float *dy, const float *mdy, const float *mdyx,
-                          void *da, void *db, float *dxlo, void *stream);
+                          const float *gamma, const float *beta, int relu, const void *dy, int dy_bf16,
+                          const float *mdy, const float *mdyx, void *da, void *db, float *dxlo, void *stream);
+/* relu != 0: y = max(0, BatchNorm(t)) - the conv -> SyncBN -> ReLU triples of the SpatialPriorModule
+ * (adapter_modules.py:217-241) with b = x = NULL; the backward recomputes y's sign from a, no mask is
+ * stored.  y / dy are fp32 or bf16 (y_bf16 / dy_bf16).
+ * vah_bn_finalize_stats: sums = [sum (C) | sum of squares (C) | element count (1)] -> mean, rstd (biased
+ * variance) and, when given, the running statistics (momentum, unbiased variance) in one launch. */
+int vah_bn_finalize_stats(const float *sums, int64_t C, float eps, float momentum, float *running_mean,
+                          float *running_var, float *mean, float *rstd, void *stream);
 
 /* ---- bf16 GEMMs of the Linear layers (csrc/gemm.hip) ----------------------------------------
  * D (M x N, row-major, leading dimension ldd; bf16, or fp32 when d_is_f32) = op(A) op(B), bf16

@@ -359,3 +359,41 @@ def test_residual_ln_pair(with_gamma, prob, C):
         t, h = fused.residual_ln(x, z, gamma, None, ln)
     t.backward(gt)
     _close(x.grad, gt, 1e-7, 'dx (t only)')
+
+
+@pytest.mark.parametrize('N,C,H,W,dt,training', [(2, 16, 64, 64, torch.bfloat16, True), (1, 8, 32, 128, torch.float32, True),
+                                                  (2, 8, 48, 32, torch.bfloat16, False)])
+def test_bn_relu_matches_reference_expression(N, C, H, W, dt, training, monkeypatch):
+    """fused.bn_relu = relu(norm(a)) (the conv -> SyncBN -> ReLU triples of the SPM): output in a's dtype,
+    gradients of a / weight / bias, running statistics."""
+    from vitadapter import fused
+    monkeypatch.setattr(fused, 'BN_RELU_MIN_NUMEL', 0)
+    torch.manual_seed(9)
+    a = (torch.randn(N, C, H, W, device='cuda') * 1.5 + 0.3).to(dt).requires_grad_(True)
+    bn, ref_bn = torch.nn.BatchNorm2d(C).cuda(), torch.nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        bn.weight.normal_(1, 0.3)
+        bn.bias.normal_(0, 0.5)
+        bn.running_mean.normal_(0.3, 0.2)
+        bn.running_var.uniform_(1.5, 3)
+    ref_bn.load_state_dict(bn.state_dict())
+    bn.train(training)
+    ref_bn.train(training)
+    g = torch.randn(N, C, H, W, device='cuda').to(dt)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        y = fused.bn_relu(bn, a)
+    assert y.dtype == dt and type(y.grad_fn).__name__ == '_BNTailBackward'
+    y.backward(g)
+    a2 = a.detach().float().requires_grad_(True)
+    yr = F.relu(ref_bn(a2))
+    yr.backward(g.float())
+    tol = 1e-2 if dt == torch.bfloat16 else 3e-5
+    _close(y, yr, tol, 'y')
+    # entries whose pre-activation sits within rounding of 0 may take the other side of the ReLU
+    diff = (a.grad.float() - a2.grad).abs()
+    lim = tol * max(1.0, a2.grad.abs().max().item())
+    assert (diff > lim).float().mean().item() <= (2e-3 if dt == torch.bfloat16 else 1e-4), diff.max().item()
+    _close(bn.weight.grad, ref_bn.weight.grad, 2e-2 if dt == torch.bfloat16 else 2e-4, 'dweight')
+    _close(bn.bias.grad, ref_bn.bias.grad, 2e-2 if dt == torch.bfloat16 else 2e-4, 'dbias')
+    _close(bn.running_mean, ref_bn.running_mean, 1e-5, 'running_mean')
+    _close(bn.running_var, ref_bn.running_var, 1e-5, 'running_var')

@@ -35,6 +35,7 @@ struct Operands {
     int a_bf16, b_bf16, scale;
     int C, H, W, Hl, Wl;
     int rows_per_block, chunks;         // chunks of rows per plane
+    int relu, y_bf16, dy_bf16;          // ReLU fused behind the normalisation; dtypes of y and dy
 };
 
 struct Tap {
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void tail_stats_kernel(Operands o, float *__re
 __global__ __launch_bounds__(256) void tail_apply_kernel(Operands o, const float *__restrict__ mean,
                                                          const float *__restrict__ rstd,
                                                          const float *__restrict__ gamma,
-                                                         const float *__restrict__ beta, float *__restrict__ y) {
+                                                         const float *__restrict__ beta, void *__restrict__ y) {
     const int64_t plane = blockIdx.x / o.chunks;
     const int chunk = blockIdx.x % o.chunks;
     const int c = (int)(plane % o.C);
@@ -159,18 +160,35 @@ __global__ __launch_bounds__(256) void tail_apply_kernel(Operands o, const float
     const int wv4 = o.W >> 2;
     const float sc = rstd[c] * (gamma ? gamma[c] : 1.f);
     const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
+    const float lo = o.relu ? 0.f : -INFINITY;
     for (int i = threadIdx.x; i < (r1 - r0) * wv4; i += 256) {
         const int yy = r0 + i / wv4, x4 = (i % wv4) * 4;
         const float4 t = sum4(o, plane, yy, x4);
-        *reinterpret_cast<float4 *>(y + (plane * o.H + yy) * o.W + x4) =
-            make_float4(t.x * sc + sh, t.y * sc + sh, t.z * sc + sh, t.w * sc + sh);
+        store4(y, (plane * o.H + yy) * o.W + x4, o.y_bf16,
+               make_float4(fmaxf(t.x * sc + sh, lo), fmaxf(t.y * sc + sh, lo), fmaxf(t.z * sc + sh, lo),
+                           fmaxf(t.w * sc + sh, lo)));
     }
+}
+
+// Gradient reaching the normalisation output: dy, masked by the fused ReLU (y recomputed, not stored).
+__device__ __forceinline__ float4 grad4(const Operands &o, const void *dy, int64_t idx, const float4 &t, float sc,
+                                        float sh) {
+    float4 g = load4(dy, idx, o.dy_bf16);
+    if (o.relu) {
+        g.x = t.x * sc + sh > 0.f ? g.x : 0.f;
+        g.y = t.y * sc + sh > 0.f ? g.y : 0.f;
+        g.z = t.z * sc + sh > 0.f ? g.z : 0.f;
+        g.w = t.w * sc + sh > 0.f ? g.w : 0.f;
+    }
+    return g;
 }
 
 // part row: (sum dy | sum dy * xhat) for the block's channel.
 __global__ __launch_bounds__(256) void tail_bwd_stats_kernel(Operands o, const float *__restrict__ mean,
                                                              const float *__restrict__ rstd,
-                                                             const float *__restrict__ dy,
+                                                             const float *__restrict__ gamma,
+                                                             const float *__restrict__ beta,
+                                                             const void *__restrict__ dy,
                                                              float *__restrict__ part) {
     __shared__ float s_red[4];
     const int64_t plane = blockIdx.x / o.chunks;
@@ -180,11 +198,12 @@ __global__ __launch_bounds__(256) void tail_bwd_stats_kernel(Operands o, const f
     const int r0 = chunk * o.rows_per_block, r1 = min(o.H, r0 + o.rows_per_block);
     const int wv4 = o.W >> 2;
     const float mu = mean[c], rs = rstd[c];
+    const float sc = rs * (gamma ? gamma[c] : 1.f), sh = (beta ? beta[c] : 0.f) - mu * sc;
     float s1 = 0.f, s2 = 0.f;
     for (int i = threadIdx.x; i < (r1 - r0) * wv4; i += 256) {
         const int yy = r0 + i / wv4, x4 = (i % wv4) * 4;
         const float4 t = sum4(o, plane, yy, x4);
-        const float4 g = *reinterpret_cast<const float4 *>(dy + (plane * o.H + yy) * o.W + x4);
+        const float4 g = grad4(o, dy, (plane * o.H + yy) * o.W + x4, t, sc, sh);
         s1 += (g.x + g.y) + (g.z + g.w);
         s2 += (g.x * (t.x - mu) + g.y * (t.y - mu)) + (g.z * (t.z - mu) + g.w * (t.w - mu));
     }
@@ -204,7 +223,8 @@ __global__ __launch_bounds__(256) void tail_bwd_stats_kernel(Operands o, const f
 __global__ __launch_bounds__(256) void tail_bwd_apply_kernel(Operands o, const float *__restrict__ mean,
                                                              const float *__restrict__ rstd,
                                                              const float *__restrict__ gamma,
-                                                             const float *__restrict__ dy,
+                                                             const float *__restrict__ beta,
+                                                             const void *__restrict__ dy,
                                                              const float *__restrict__ mdy,
                                                              const float *__restrict__ mdyx, void *__restrict__ da,
                                                              void *__restrict__ db, float *__restrict__ dxlo) {
@@ -217,12 +237,13 @@ __global__ __launch_bounds__(256) void tail_bwd_apply_kernel(Operands o, const f
     const int wv4 = o.W >> 2;
     const float mu = mean[c], rs = rstd[c];
     const float k = rs * (gamma ? gamma[c] : 1.f), m1 = mdy[c], m2 = mdyx[c];
+    const float sh = (beta ? beta[c] : 0.f) - mu * k;
     const bool want_lo = dxlo != nullptr && o.x != nullptr;
     for (int i = threadIdx.x; i < rows * wv4; i += 256) {
         const int yy = r0 + i / wv4, x4 = (i % wv4) * 4;
         const int64_t idx = (plane * o.H + yy) * o.W + x4;
         const float4 t = sum4(o, plane, yy, x4);
-        const float4 g = *reinterpret_cast<const float4 *>(dy + idx);
+        const float4 g = grad4(o, dy, idx, t, k, sh);
         const float4 d = make_float4(k * (g.x - m1 - (t.x - mu) * rs * m2), k * (g.y - m1 - (t.y - mu) * rs * m2),
                                      k * (g.z - m1 - (t.z - mu) * rs * m2), k * (g.w - m1 - (t.w - mu) * rs * m2));
         if (da) store4(da, idx, o.a_bf16, d);
@@ -289,6 +310,26 @@ __global__ __launch_bounds__(256) void tail_finalize(const float *__restrict__ p
     }
 }
 
+// sums = [sum t (C) | sum t^2 (C) | count (1)]  ->  mean, rstd (biased variance, as the normalisation
+// uses) and the running statistics (unbiased variance, momentum) in ONE small launch; done with
+// separate torch ops this bookkeeping was ~10 kernel launches per BatchNorm call.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restrict__ sums, int C, float eps, float momentum,
+                                                          float *__restrict__ running_mean,
+                                                          float *__restrict__ running_var, float *__restrict__ mean,
+                                                          float *__restrict__ rstd) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float count = sums[2 * C];
+    const float mu = sums[c] / count;
+    const float var = fmaxf(sums[C + c] / count - mu * mu, 0.f);
+    mean[c] = mu;
+    rstd[c] = rsqrtf(var + eps);
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (count / fmaxf(count - 1.f, 1.f));
+    }
+}
+
 int fill_operands(const char *fn, Operands &o, const void *a, int a_bf16, const void *b, int b_bf16, const float *x,
                   int scale, int64_t N, int64_t C, int64_t H, int64_t W) {
     if (N < 1 || C < 1 || H < 1 || W < 4 || W % 4 || W > kTilePx) return fail(VAH_E_SHAPE, "%s: bad shape", fn);
@@ -298,6 +339,7 @@ int fill_operands(const char *fn, Operands &o, const void *a, int a_bf16, const 
     if (!a) return fail(VAH_E_NULL, "%s: null pointer", fn);
     if (((uintptr_t)a | (uintptr_t)b) % 8 || (uintptr_t)x % 16 || (!a_bf16 && (uintptr_t)a % 16) || (b && !b_bf16 && (uintptr_t)b % 16))
         return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    o.relu = o.y_bf16 = o.dy_bf16 = 0;
     o.a = a;
     o.b = b;
     o.x = x;
@@ -348,14 +390,16 @@ int vah_bn_tail_stats(const void *a, int a_bf16, const void *b, int b_bf16, cons
 
 int vah_bn_tail_apply(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale, int64_t N,
                       int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd, const float *gamma,
-                      const float *beta, float *y, void *stream) {
+                      const float *beta, int relu, void *y, int y_bf16, void *stream) {
     using namespace vah;
     clear_error();
     const char *fn = "vah_bn_tail_apply";
     Operands o;
     if (int rc = fill_operands(fn, o, a, a_bf16, b, b_bf16, x, scale, N, C, H, W)) return rc;
     if (!mean || !rstd || !y) return fail(VAH_E_NULL, "%s: null pointer", fn);
-    if ((uintptr_t)y % 16) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    if ((uintptr_t)y % (y_bf16 ? 8 : 16)) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    o.relu = relu != 0;
+    o.y_bf16 = y_bf16 != 0;
     hipStream_t st = (hipStream_t)stream;
     LaunchScope scope("bn_tail_apply", N * C * H * W * ((a_bf16 ? 2 : 4) + (b ? (b_bf16 ? 2 : 4) : 0) + 4), st);
     hipLaunchKernelGGL(tail_apply_kernel, dim3((unsigned)(N * C * o.chunks)), dim3(256), 0, st, o, mean, rstd, gamma, beta, y);
@@ -363,34 +407,41 @@ int vah_bn_tail_apply(const void *a, int a_bf16, const void *b, int b_bf16, cons
 }
 
 int vah_bn_tail_bwd_stats(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale, int64_t N,
-                          int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd, const float *dy,
-                          float *sums, float *ws, void *stream) {
+                          int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd, const float *gamma,
+                          const float *beta, int relu, const void *dy, int dy_bf16, float *sums, float *ws,
+                          void *stream) {
     using namespace vah;
     clear_error();
     const char *fn = "vah_bn_tail_bwd_stats";
     Operands o;
     if (int rc = fill_operands(fn, o, a, a_bf16, b, b_bf16, x, scale, N, C, H, W)) return rc;
     if (!mean || !rstd || !dy || !sums || !ws) return fail(VAH_E_NULL, "%s: null pointer", fn);
-    if ((uintptr_t)dy % 16) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    if ((uintptr_t)dy % (dy_bf16 ? 8 : 16)) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    o.relu = relu != 0;
+    o.dy_bf16 = dy_bf16 != 0;
     hipStream_t st = (hipStream_t)stream;
     const int nparts = (int)N * o.chunks;
     LaunchScope scope("bn_tail_bwd_stats", N * C * H * W * ((a_bf16 ? 2 : 4) + (b ? (b_bf16 ? 2 : 4) : 0) + 4), st);
-    hipLaunchKernelGGL(tail_bwd_stats_kernel, dim3((unsigned)(N * C * o.chunks)), dim3(256), 0, st, o, mean, rstd, dy, ws);
+    hipLaunchKernelGGL(tail_bwd_stats_kernel, dim3((unsigned)(N * C * o.chunks)), dim3(256), 0, st, o, mean, rstd, gamma, beta,
+                       dy, ws);
     hipLaunchKernelGGL(tail_finalize, dim3((unsigned)((2 * C + 31) / 32)), dim3(256), 0, st, ws, nparts, (int)(2 * C), sums);
     return check_launch(fn);
 }
 
 int vah_bn_tail_bwd_apply(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale, int64_t N,
                           int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd, const float *gamma,
-                          const float *dy, const float *mdy, const float *mdyx, void *da, void *db, float *dxlo,
-                          void *stream) {
+                          const float *beta, int relu, const void *dy, int dy_bf16, const float *mdy, const float *mdyx,
+                          void *da, void *db, float *dxlo, void *stream) {
     using namespace vah;
     clear_error();
     const char *fn = "vah_bn_tail_bwd_apply";
     Operands o;
     if (int rc = fill_operands(fn, o, a, a_bf16, b, b_bf16, x, scale, N, C, H, W)) return rc;
     if (!mean || !rstd || !dy || !mdy || !mdyx) return fail(VAH_E_NULL, "%s: null pointer", fn);
-    if (((uintptr_t)dy | (uintptr_t)dxlo) % 16 || ((uintptr_t)da | (uintptr_t)db) % 8) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    if ((uintptr_t)dy % (dy_bf16 ? 8 : 16) || (uintptr_t)dxlo % 16 || ((uintptr_t)da | (uintptr_t)db) % 8)
+        return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    o.relu = relu != 0;
+    o.dy_bf16 = dy_bf16 != 0;
     hipStream_t st = (hipStream_t)stream;
     size_t smem = 0;
     if (dxlo && x && scale > 1) smem = (size_t)o.rows_per_block * (o.W + o.Wl) * sizeof(float);
@@ -399,7 +450,22 @@ int vah_bn_tail_bwd_apply(const void *a, int a_bf16, const void *b, int b_bf16, 
     if (smem > 64 * 1024)
         (void)hipFuncSetAttribute((const void *)tail_bwd_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     hipLaunchKernelGGL(tail_bwd_apply_kernel, dim3((unsigned)(N * C * o.chunks)), dim3(256), smem, st, o, mean, rstd, gamma,
-                       dy, mdy, mdyx, da, db, dxlo);
+                       beta, dy, mdy, mdyx, da, db, dxlo);
+    return check_launch(fn);
+}
+
+// sums = [sum (C) | sum of squares (C) | element count (1)] (as written by vah_bn_tail_stats plus the
+// count, all-reduced over the ranks for SyncBatchNorm) -> mean, rstd; running statistics updated in
+// place when given (momentum, unbiased variance), as torch.nn.BatchNorm does in training.
+int vah_bn_finalize_stats(const float *sums, int64_t C, float eps, float momentum, float *running_mean,
+                          float *running_var, float *mean, float *rstd, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_bn_finalize_stats";
+    if (C < 1) return fail(VAH_E_SHAPE, "%s: bad C", fn);
+    if (!sums || !mean || !rstd || ((running_mean != nullptr) != (running_var != nullptr))) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sums, (int)C, eps,
+                       momentum, running_mean, running_var, mean, rstd);
     return check_launch(fn);
 }
 

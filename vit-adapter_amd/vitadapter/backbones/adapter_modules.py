@@ -233,11 +233,27 @@ class SpatialPriorModule(nn.Module):
         self.fc3 = nn.Conv2d(4 * inplanes, embed_dim, kernel_size=1, stride=1, padding=0, bias=True)
         self.fc4 = nn.Conv2d(4 * inplanes, embed_dim, kernel_size=1, stride=1, padding=0, bias=True)
 
+    @staticmethod
+    def _run(seq, x):
+        """``seq(x)`` with every (BatchNorm, ReLU) pair of the Sequential as one fused op."""
+        mods = list(seq)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if (isinstance(m, nn.modules.batchnorm._BatchNorm) and i + 1 < len(mods)
+                    and isinstance(mods[i + 1], nn.ReLU)):
+                x = fused.bn_relu(m, x)
+                i += 2
+            else:
+                x = m(x)
+                i += 1
+        return x
+
     def _body(self, x):
-        c1 = self.stem(x)
-        c2 = self.conv2(c1)
-        c3 = self.conv3(c2)
-        c4 = self.conv4(c3)
+        c1 = self._run(self.stem, x)
+        c2 = self._run(self.conv2, c1)
+        c3 = self._run(self.conv3, c2)
+        c4 = self._run(self.conv4, c3)
         c1 = self.fc1(c1)
         tokens = [f(c).flatten(2).transpose(1, 2) for f, c in
                   ((self.fc2, c2), (self.fc3, c3), (self.fc4, c4))]

@@ -12,7 +12,8 @@ import torch.nn.functional as F
 
 import _vah
 
-ENABLED = {'layer_norm': True, 'residual': True, 'residual_ln': True, 'dwconv': True, 'linear': True, 'bn_tail': True}
+ENABLED = {'layer_norm': True, 'residual': True, 'residual_ln': True, 'dwconv': True, 'linear': True, 'bn_tail': True,
+           'bn_relu': True}
 for _k in os.environ.get('VAH_FUSED_DISABLE', '').split(','):      # e.g. VAH_FUSED_DISABLE=residual_ln,bn_tail (A/B runs)
     if _k:
         ENABLED[_k.strip()] = False
@@ -457,8 +458,11 @@ def _sync_group(norm):
 
 
 class _BNTail(torch.autograd.Function):
+    """y = [relu] BatchNorm(a + b + upsample(x)): statistics pass, one bookkeeping launch (mean, rstd,
+    running statistics), normalise pass; SyncBatchNorm all-reduces the sums in between."""
+
     @staticmethod
-    def forward(ctx, a, b, x, weight, bias, norm, scale):
+    def forward(ctx, a, b, x, weight, bias, norm, scale, relu, out_dtype):
         N, C, H, W = a.shape
         a = a.contiguous()
         b = b.contiguous() if b is not None else None
@@ -469,58 +473,65 @@ class _BNTail(torch.autograd.Function):
                scale, N, C, H, W)
         training = norm.training or norm.running_mean is None
         group = _sync_group(norm) if training else None
+        w = weight.detach().float().contiguous() if weight is not None else None
+        bb = bias.detach().float().contiguous() if bias is not None else None
         with torch.cuda.device(dev):
             if training:
                 sums = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
                 ws = torch.empty(_vah.lib.vah_bn_tail_ws_floats(C), dtype=torch.float32, device=dev)
                 _vah.check(_vah.lib.vah_bn_tail_stats(*ops, sums.data_ptr(), ws.data_ptr(), st), 'bn_tail_stats')
-                sums[2 * C] = float(N * H * W)
+                sums[2 * C:].fill_(float(N * H * W))
                 if group is not None:
                     import torch.distributed as dist
                     dist.all_reduce(sums, group=group)
-                count = sums[2 * C]
-                mean = sums[:C] / count
-                var = (sums[C:2 * C] / count - mean * mean).clamp_(min=0.)
-                if norm.running_mean is not None:
+                mean = torch.empty(C, dtype=torch.float32, device=dev)
+                rstd = torch.empty(C, dtype=torch.float32, device=dev)
+                track = norm.running_mean is not None
+                _vah.check(_vah.lib.vah_bn_finalize_stats(
+                    sums.data_ptr(), C, float(norm.eps), float(norm.momentum),
+                    norm.running_mean.data_ptr() if track else None, norm.running_var.data_ptr() if track else None,
+                    mean.data_ptr(), rstd.data_ptr(), st), 'bn_finalize_stats')
+                if track:
                     with torch.no_grad():
-                        m = norm.momentum
                         norm.num_batches_tracked += 1
-                        if m is None:
-                            m = 1.0 / float(norm.num_batches_tracked)
-                        norm.running_mean.mul_(1 - m).add_(mean, alpha=m)
-                        norm.running_var.mul_(1 - m).add_(var * (count / (count - 1)), alpha=m)
+                count = sums[2 * C:]
             else:
                 count = None
-                mean, var = norm.running_mean.float(), norm.running_var.float()
-            rstd = torch.rsqrt(var + norm.eps)
-            mean = mean.contiguous()
-            w = weight.detach().float().contiguous() if weight is not None else None
-            bb = bias.detach().float().contiguous() if bias is not None else None
-            y = torch.empty((N, C, H, W), dtype=torch.float32, device=dev)
+                mean = norm.running_mean.float().contiguous()
+                rstd = torch.rsqrt(norm.running_var.float() + norm.eps)
+            y = torch.empty((N, C, H, W), dtype=out_dtype, device=dev)
             _vah.check(_vah.lib.vah_bn_tail_apply(
                 *ops, mean.data_ptr(), rstd.data_ptr(), w.data_ptr() if w is not None else None,
-                bb.data_ptr() if bb is not None else None, y.data_ptr(), st), 'bn_tail_apply')
-        ctx.save_for_backward(a, b, x, mean, rstd, w, count)
-        ctx.meta = (scale, training, group, b.dtype if b is not None else None, weight is not None, bias is not None)
+                bb.data_ptr() if bb is not None else None, int(relu), y.data_ptr(),
+                int(out_dtype == torch.bfloat16), st), 'bn_tail_apply')
+        ctx.save_for_backward(a, b, x, mean, rstd, w, bb, count)
+        ctx.meta = (scale, training, group, weight is not None, bias is not None, relu)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        a, b, x, mean, rstd, w, count = ctx.saved_tensors
-        scale, training, group, _, has_w, has_b = ctx.meta
+        a, b, x, mean, rstd, w, bb, count = ctx.saved_tensors
+        scale, training, group, has_w, has_b, relu = ctx.meta
         N, C, H, W = a.shape
-        dy = dy.contiguous().float()
+        dy = dy.contiguous()
+        if dy.dtype not in (torch.float32, torch.bfloat16):
+            dy = dy.float()
+        dy_bf16 = int(dy.dtype == torch.bfloat16)
         dev, st = a.device, _stream(a)
         ops = (a.data_ptr(), int(a.dtype == torch.bfloat16), b.data_ptr() if b is not None else None,
                int(b is not None and b.dtype == torch.bfloat16), x.data_ptr() if x is not None else None,
                scale, N, C, H, W)
+        wp = w.data_ptr() if w is not None else None
+        bp = bb.data_ptr() if bb is not None else None
         with torch.cuda.device(dev):
             sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
             ws = torch.empty(_vah.lib.vah_bn_tail_ws_floats(C), dtype=torch.float32, device=dev)
-            _vah.check(_vah.lib.vah_bn_tail_bwd_stats(*ops, mean.data_ptr(), rstd.data_ptr(), dy.data_ptr(),
-                                                      sums.data_ptr(), ws.data_ptr(), st), 'bn_tail_bwd_stats')
-            dweight = sums[C:].clone() if has_w else None
-            dbias = sums[:C].clone() if has_b else None
+            _vah.check(_vah.lib.vah_bn_tail_bwd_stats(*ops, mean.data_ptr(), rstd.data_ptr(), wp, bp, int(relu),
+                                                      dy.data_ptr(), dy_bf16, sums.data_ptr(), ws.data_ptr(), st),
+                       'bn_tail_bwd_stats')
+            local = sums.clone() if (training and group is not None) else sums      # dweight / dbias are per-rank sums
+            dweight = local[C:] if has_w else None
+            dbias = local[:C] if has_b else None
             if training:
                 if group is not None:
                     import torch.distributed as dist
@@ -536,11 +547,20 @@ class _BNTail(torch.autograd.Function):
                 dx = torch.zeros_like(x) if scale > 1 else torch.empty_like(x)
             if da is not None or db is not None or dx is not None:
                 _vah.check(_vah.lib.vah_bn_tail_bwd_apply(
-                    *ops, mean.data_ptr(), rstd.data_ptr(), w.data_ptr() if w is not None else None,
-                    dy.data_ptr(), means[:C].data_ptr(), means[C:].data_ptr(),
+                    *ops, mean.data_ptr(), rstd.data_ptr(), wp, bp, int(relu), dy.data_ptr(), dy_bf16,
+                    means[:C].data_ptr(), means[C:].data_ptr(),
                     da.data_ptr() if da is not None else None, db.data_ptr() if db is not None else None,
                     dx.data_ptr() if dx is not None else None, st), 'bn_tail_bwd_apply')
-        return da, db, dx, dweight, dbias, None, None
+        return da, db, dx, dweight, dbias, None, None, None, None
+
+
+def _bn_fusable(norm, a):
+    return (isinstance(norm, torch.nn.modules.batchnorm._BatchNorm) and a.is_cuda and _bf16_autocast()
+            and a.dim() == 4 and a.dtype in (torch.bfloat16, torch.float32) and a.shape[3] <= 8192
+            and a.numel() > 0 and norm.momentum is not None
+            and (not norm.training or a.shape[0] * a.shape[2] * a.shape[3] > 1)
+            and (norm.training or norm.running_mean is not None)
+            and (norm.weight is None or norm.weight.dtype == torch.float32))
 
 
 def halve(x):
@@ -558,19 +578,26 @@ def bn_tail(norm, a, b=None, x=None, scale=1):
     """``norm(a + b + F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=False))``
     for a (Sync)BatchNorm2d ``norm`` - the output tail of the backbone (ref vit_adapter.py:106-127);
     ``b`` / ``x`` optional, ``scale == 1`` adds ``x`` as it is."""
-    bn = isinstance(norm, torch.nn.modules.batchnorm._BatchNorm)
-    if (ENABLED['bn_tail'] and bn and a.is_cuda and _bf16_autocast() and a.dim() == 4 and x is not None
-            and a.dtype in (torch.bfloat16, torch.float32) and (b is None or (b.shape == a.shape and b.dtype in
-                                                                               (torch.bfloat16, torch.float32)))
+    if (ENABLED['bn_tail'] and _bn_fusable(norm, a) and x is not None
+            and (b is None or (b.shape == a.shape and b.dtype in (torch.bfloat16, torch.float32)))
             and scale in (1, 2, 4, 8) and a.shape[3] % (4 * scale) == 0 and a.shape[2] % scale == 0
-            and a.shape[3] <= 8192 and tuple(x.shape) == (a.shape[0], a.shape[1], a.shape[2] // scale, a.shape[3] // scale)
-            and x.dtype in (torch.bfloat16, torch.float32) and a.numel() > 0
-            and (not norm.training or a.shape[0] * a.shape[2] * a.shape[3] > 1)
-            and (norm.training or norm.running_mean is not None)
-            and (norm.weight is None or norm.weight.dtype == torch.float32)):
-        return _BNTail.apply(a, b, x, norm.weight, norm.bias, norm, scale)
+            and tuple(x.shape) == (a.shape[0], a.shape[1], a.shape[2] // scale, a.shape[3] // scale)
+            and x.dtype in (torch.bfloat16, torch.float32)):
+        return _BNTail.apply(a, b, x, norm.weight, norm.bias, norm, scale, False, torch.float32)
     t = a if b is None else a + b
     if x is not None:
         t = t + (x if scale == 1 else F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=False))
     return norm(t)
 
+
+BN_RELU_MIN_NUMEL = int(os.environ.get('VAH_BN_RELU_MIN_NUMEL', 8 << 20))
+
+
+def bn_relu(norm, a):
+    """``relu(norm(a))`` for the conv -> SyncBatchNorm -> ReLU triples of the SpatialPriorModule
+    (adapter_modules.py:217-241): statistics pass + normalise-and-clamp pass, output in a's dtype;
+    the backward recomputes the ReLU mask from ``a``."""
+    # the two-pass form pays from a few million elements on (below that MIOpen's single kernel wins)
+    if ENABLED['bn_relu'] and _bn_fusable(norm, a) and a.shape[3] % 4 == 0 and a.numel() >= BN_RELU_MIN_NUMEL:
+        return _BNTail.apply(a, None, None, norm.weight, norm.bias, norm, 1, True, a.dtype)
+    return F.relu(norm(a))
