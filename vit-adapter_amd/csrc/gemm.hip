@@ -265,13 +265,13 @@ hipblasStatus_t choose_for_split(State &S, const Call &c, Problem &p, int split,
     // coarse pass over everything, then a longer look at the best few
     std::vector<std::pair<float, size_t>> timed;
     for (size_t i = 0; i < cand.size(); ++i) {
-        const float us = time_algo(S, c, p, cand[i].algo, cand[i].workspaceSize, split, e0, e1, 2);
+        const float us = time_algo(S, c, p, cand[i].algo, cand[i].workspaceSize, split, e0, e1, 3);
         if (us > 0.f) timed.emplace_back(us, i);
     }
     std::sort(timed.begin(), timed.end());
     for (size_t j = 0; j < std::min<size_t>(timed.size(), 4); ++j) {
         const size_t i = timed[j].second;
-        const float us = time_algo(S, c, p, cand[i].algo, cand[i].workspaceSize, split, e0, e1, 8);
+        const float us = time_algo(S, c, p, cand[i].algo, cand[i].workspaceSize, split, e0, e1, 20);
         if (us > 0.f && (best < 0.f || us < best)) {
             best = us;
             best_i = i;
