@@ -271,21 +271,28 @@ int vah_colsum_bf16(const void *g_bf16, int64_t rows, int64_t C, float *out, flo
  * The caller owns the statistics between the passes (SyncBatchNorm all-reduces them there). */
 int64_t vah_bn_tail_ws_floats(int64_t C);
 int vah_bn_tail_stats(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale,
-                      int64_t N, int64_t C, int64_t H, int64_t W, float *sums, float *ws, void *stream);
+                      int64_t N, int64_t C, int64_t H, int64_t W, const float *shift, float *sums, float *ws,
+                      void *stream);
 int vah_bn_tail_apply(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale,
                       int64_t N, int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd,
-                      const float *gamma, const float *beta, int relu, void *y, int y_bf16, void *stream);
+                      const float *gamma, const float *beta, int relu, const float *shift, void *y, int y_bf16,
+                      void *stream);
 int vah_bn_tail_bwd_stats(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale,
                           int64_t N, int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd,
-                          const float *gamma, const float *beta, int relu, const void *dy, int dy_bf16,
-                          float *sums, float *ws, void *stream);
+                          const float *gamma, const float *beta, int relu, const float *shift, const void *dy,
+                          int dy_bf16, float *sums, float *ws, void *stream);
 int vah_bn_tail_bwd_apply(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale,
                           int64_t N, int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd,
-                          const float *gamma, const float *beta, int relu, const void *dy, int dy_bf16,
-                          const float *mdy, const float *mdyx, void *da, void *db, float *dxlo, void *stream);
+                          const float *gamma, const float *beta, int relu, const float *shift, const void *dy,
+                          int dy_bf16, const float *mdy, const float *mdyx, void *da, void *db, float *dxlo,
+                          void *stream);
 /* relu != 0: y = max(0, BatchNorm(t)) - the conv -> SyncBN -> ReLU triples of the SpatialPriorModule
  * (adapter_modules.py:217-241) with b = x = NULL; the backward recomputes y's sign from a, no mask is
  * stored.  y / dy are fp32 or bf16 (y_bf16 / dy_bf16).
+ * shift (C floats or NULL): a per-channel constant added to the sum - the biases of the convolutions
+ * that produce a and b (ConvTranspose2d `up`, the SPM's 1x1 `fc1`): applying them here instead of in
+ * 100 M-element bias-add passes (and their bias-gradient reductions) changes nothing, BatchNorm
+ * subtracts the channel mean anyway.
  * vah_bn_finalize_stats: sums = [sum (C) | sum of squares (C) | element count (1)] -> mean, rstd (biased
  * variance) and, when given, the running statistics (momentum, unbiased variance) in one launch. */
 int vah_bn_finalize_stats(const float *sums, int64_t C, float eps, float momentum, float *running_mean,

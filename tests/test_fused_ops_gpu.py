@@ -285,21 +285,27 @@ def test_bn_tail_matches_reference_expression(N, C, H, W, scale, with_b, a_bf16,
     bn.train(training)
     ref_bn.train(training)
     g = torch.randn(N, C, H, W, device='cuda')
+    # a per-channel shift (folded conv biases) rides along in every case
+    shift = (torch.randn(C, device='cuda') * 0.7).requires_grad_(True)
     with torch.autocast('cuda', dtype=torch.bfloat16):
-        y = fused.bn_tail(bn, a, b, x, scale)
+        y = fused.bn_tail(bn, a, b, x, scale, shift)
     assert y.dtype == torch.float32
     y.backward(g)
-    got = dict(a=a.grad.clone(), x=x.grad.clone(), w=bn.weight.grad.clone(), bias=bn.bias.grad.clone())
+    got = dict(a=a.grad.clone(), x=x.grad.clone(), w=bn.weight.grad.clone(), bias=bn.bias.grad.clone(),
+               shift=shift.grad.clone())
     if with_b:
         got['b'] = b.grad.clone()
     a2 = a.detach().float().requires_grad_(True)
     b2 = b.detach().float().requires_grad_(True) if with_b else None
     x2 = x.detach().clone().requires_grad_(True)
+    shift2 = shift.detach().clone().requires_grad_(True)
     t = a2 + b2 if with_b else a2
+    t = t + shift2.view(1, -1, 1, 1)
     t = t + (x2 if scale == 1 else F.interpolate(x2, scale_factor=scale, mode='bilinear', align_corners=False))
     yr = ref_bn(t)
     yr.backward(g)
     _close(y, yr, 2e-5, 'y')
+    assert (got['shift'] - shift2.grad).abs().max().item() <= 2e-3 * max(1.0, g.abs().sum((0, 2, 3)).max().item() * 1e-2)
     _close(got['a'], a2.grad, 1e-2 if a_bf16 else 2e-5, 'da')
     if with_b:
         _close(got['b'], b2.grad, 1e-2, 'db')

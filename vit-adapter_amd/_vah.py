@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -89,10 +89,10 @@ lib.vah_gemm_library_version.restype = _i64
 _tail_in = [_p, _int, _p, _int, _p, _int, _i64, _i64, _i64, _i64]
 lib.vah_bn_tail_ws_floats.argtypes = [_i64]
 lib.vah_bn_tail_ws_floats.restype = _i64
-lib.vah_bn_tail_stats.argtypes = _tail_in + [_p, _p, _p]
-lib.vah_bn_tail_apply.argtypes = _tail_in + [_p, _p, _p, _p, _int, _p, _int, _p]
-lib.vah_bn_tail_bwd_stats.argtypes = _tail_in + [_p, _p, _p, _p, _int, _p, _int, _p, _p, _p]
-lib.vah_bn_tail_bwd_apply.argtypes = _tail_in + [_p, _p, _p, _p, _int, _p, _int, _p, _p, _p, _p, _p, _p]
+lib.vah_bn_tail_stats.argtypes = _tail_in + [_p, _p, _p, _p]
+lib.vah_bn_tail_apply.argtypes = _tail_in + [_p, _p, _p, _p, _int, _p, _p, _int, _p]
+lib.vah_bn_tail_bwd_stats.argtypes = _tail_in + [_p, _p, _p, _p, _int, _p, _p, _int, _p, _p, _p]
+lib.vah_bn_tail_bwd_apply.argtypes = _tail_in + [_p, _p, _p, _p, _int, _p, _p, _int, _p, _p, _p, _p, _p, _p]
 lib.vah_bn_finalize_stats.argtypes = [_p, _i64, _f, _f, _p, _p, _p, _p, _p]
 lib.vah_reduce_ws_floats.argtypes = [_i64]
 lib.vah_reduce_ws_floats.restype = _i64

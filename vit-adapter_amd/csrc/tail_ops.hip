@@ -36,6 +36,7 @@ struct Operands {
     int C, H, W, Hl, Wl;
     int rows_per_block, chunks;         // chunks of rows per plane
     int relu, y_bf16, dy_bf16;          // ReLU fused behind the normalisation; dtypes of y and dy
+    const float *shift;                 // optional per-channel constant added to the sum (conv biases)
 };
 
 struct Tap {
@@ -78,6 +79,13 @@ __device__ __forceinline__ void store4(void *p, int64_t idx, int is_bf16, float4
 __device__ __forceinline__ float4 sum4(const Operands &o, int64_t plane, int y, int x4) {
     const int64_t idx = (plane * o.H + y) * o.W + x4;
     float4 t = load4(o.a, idx, o.a_bf16);
+    if (o.shift) {
+        const float sft = o.shift[plane % o.C];
+        t.x += sft;
+        t.y += sft;
+        t.z += sft;
+        t.w += sft;
+    }
     if (o.b) {
         const float4 v = load4(o.b, idx, o.b_bf16);
         t.x += v.x;
@@ -340,6 +348,7 @@ int fill_operands(const char *fn, Operands &o, const void *a, int a_bf16, const 
     if (((uintptr_t)a | (uintptr_t)b) % 8 || (uintptr_t)x % 16 || (!a_bf16 && (uintptr_t)a % 16) || (b && !b_bf16 && (uintptr_t)b % 16))
         return fail(VAH_E_ALIGN, "%s: misaligned", fn);
     o.relu = o.y_bf16 = o.dy_bf16 = 0;
+    o.shift = nullptr;
     o.a = a;
     o.b = b;
     o.x = x;
@@ -373,13 +382,14 @@ extern "C" {
 int64_t vah_bn_tail_ws_floats(int64_t C) { return (int64_t)vah::kTailParts * 2 * C; }
 
 int vah_bn_tail_stats(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale, int64_t N,
-                      int64_t C, int64_t H, int64_t W, float *sums, float *ws, void *stream) {
+                      int64_t C, int64_t H, int64_t W, const float *shift, float *sums, float *ws, void *stream) {
     using namespace vah;
     clear_error();
     const char *fn = "vah_bn_tail_stats";
     Operands o;
     if (int rc = fill_operands(fn, o, a, a_bf16, b, b_bf16, x, scale, N, C, H, W)) return rc;
     if (!sums || !ws) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    o.shift = shift;
     hipStream_t st = (hipStream_t)stream;
     const int nparts = (int)N * o.chunks;
     LaunchScope scope("bn_tail_stats", N * C * H * W * ((a_bf16 ? 2 : 4) + (b ? (b_bf16 ? 2 : 4) : 0)), st);
@@ -390,7 +400,7 @@ int vah_bn_tail_stats(const void *a, int a_bf16, const void *b, int b_bf16, cons
 
 int vah_bn_tail_apply(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale, int64_t N,
                       int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd, const float *gamma,
-                      const float *beta, int relu, void *y, int y_bf16, void *stream) {
+                      const float *beta, int relu, const float *shift, void *y, int y_bf16, void *stream) {
     using namespace vah;
     clear_error();
     const char *fn = "vah_bn_tail_apply";
@@ -400,6 +410,7 @@ int vah_bn_tail_apply(const void *a, int a_bf16, const void *b, int b_bf16, cons
     if ((uintptr_t)y % (y_bf16 ? 8 : 16)) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
     o.relu = relu != 0;
     o.y_bf16 = y_bf16 != 0;
+    o.shift = shift;
     hipStream_t st = (hipStream_t)stream;
     LaunchScope scope("bn_tail_apply", N * C * H * W * ((a_bf16 ? 2 : 4) + (b ? (b_bf16 ? 2 : 4) : 0) + 4), st);
     hipLaunchKernelGGL(tail_apply_kernel, dim3((unsigned)(N * C * o.chunks)), dim3(256), 0, st, o, mean, rstd, gamma, beta, y);
@@ -408,8 +419,8 @@ int vah_bn_tail_apply(const void *a, int a_bf16, const void *b, int b_bf16, cons
 
 int vah_bn_tail_bwd_stats(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale, int64_t N,
                           int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd, const float *gamma,
-                          const float *beta, int relu, const void *dy, int dy_bf16, float *sums, float *ws,
-                          void *stream) {
+                          const float *beta, int relu, const float *shift, const void *dy, int dy_bf16, float *sums,
+                          float *ws, void *stream) {
     using namespace vah;
     clear_error();
     const char *fn = "vah_bn_tail_bwd_stats";
@@ -419,6 +430,7 @@ int vah_bn_tail_bwd_stats(const void *a, int a_bf16, const void *b, int b_bf16, 
     if ((uintptr_t)dy % (dy_bf16 ? 8 : 16)) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
     o.relu = relu != 0;
     o.dy_bf16 = dy_bf16 != 0;
+    o.shift = shift;
     hipStream_t st = (hipStream_t)stream;
     const int nparts = (int)N * o.chunks;
     LaunchScope scope("bn_tail_bwd_stats", N * C * H * W * ((a_bf16 ? 2 : 4) + (b ? (b_bf16 ? 2 : 4) : 0) + 4), st);
@@ -430,8 +442,8 @@ int vah_bn_tail_bwd_stats(const void *a, int a_bf16, const void *b, int b_bf16, 
 
 int vah_bn_tail_bwd_apply(const void *a, int a_bf16, const void *b, int b_bf16, const float *x, int scale, int64_t N,
                           int64_t C, int64_t H, int64_t W, const float *mean, const float *rstd, const float *gamma,
-                          const float *beta, int relu, const void *dy, int dy_bf16, const float *mdy, const float *mdyx,
-                          void *da, void *db, float *dxlo, void *stream) {
+                          const float *beta, int relu, const float *shift, const void *dy, int dy_bf16, const float *mdy,
+                          const float *mdyx, void *da, void *db, float *dxlo, void *stream) {
     using namespace vah;
     clear_error();
     const char *fn = "vah_bn_tail_bwd_apply";
@@ -442,6 +454,7 @@ int vah_bn_tail_bwd_apply(const void *a, int a_bf16, const void *b, int b_bf16, 
         return fail(VAH_E_ALIGN, "%s: misaligned", fn);
     o.relu = relu != 0;
     o.dy_bf16 = dy_bf16 != 0;
+    o.shift = shift;
     hipStream_t st = (hipStream_t)stream;
     size_t smem = 0;
     if (dxlo && x && scale > 1) smem = (size_t)o.rows_per_block * (o.W + o.Wl) * sizeof(float);

@@ -15,6 +15,7 @@ from functools import partial
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 import torch.utils.checkpoint as cp
 from ops.modules import MSDeformAttn
 
@@ -254,12 +255,20 @@ class SpatialPriorModule(nn.Module):
         c2 = self._run(self.conv2, c1)
         c3 = self._run(self.conv3, c2)
         c4 = self._run(self.conv4, c3)
-        c1 = self.fc1(c1)
+        # bias_free_c1: the 1x1 conv to embed_dim without its bias - the caller folds fc1.bias into the
+        # BatchNorm tail (fused.bn_tail shift) instead of a 100 M-element bias-add pass
+        c1 = F.conv2d(c1, self.fc1.weight, None) if self._bias_free_c1 else self.fc1(c1)
         tokens = [f(c).flatten(2).transpose(1, 2) for f, c in
                   ((self.fc2, c2), (self.fc3, c3), (self.fc4, c4))]
         return (c1, *tokens)
 
-    def forward(self, x):
-        if self.with_cp and x.requires_grad:
-            return cp.checkpoint(self._body, x, use_reentrant=False)
-        return self._body(x)
+    _bias_free_c1 = False
+
+    def forward(self, x, bias_free_c1=False):
+        self._bias_free_c1 = bool(bias_free_c1)
+        try:
+            if self.with_cp and x.requires_grad:
+                return cp.checkpoint(self._body, x, use_reentrant=False)
+            return self._body(x)
+        finally:
+            self._bias_free_c1 = False

@@ -65,7 +65,9 @@ class BEiTAdapter(BEiT):
         fused.refresh_linear_copies(self)
         deform_inputs1, deform_inputs2 = deform_inputs(x)
 
-        c1, c2, c3, c4 = self.spm(x)
+        # fused tail: the biases of spm.fc1 and self.up reach norm1 as a per-channel shift
+        fold = self.add_vit_feature and fused.tail_takes_conv_bias(self.norm1, x)
+        c1, c2, c3, c4 = self.spm(x, bias_free_c1=fold)
         c2, c3, c4 = self._add_level_embed(c2, c3, c4)
         n2, n3 = c2.size(1), c3.size(1)
         c = torch.cat([c2, c3, c4], dim=1)
@@ -90,7 +92,9 @@ class BEiTAdapter(BEiT):
         if self.add_vit_feature:
             x1, x2, x3, x4 = outs
             c4 = c4 + fused.halve(x4)
-            return [fused.bn_tail(self.norm1, self.up(c2), c1, x1, 4), fused.bn_tail(self.norm2, c2, None, x2, 2),
+            up = F.conv_transpose2d(c2, self.up.weight, None, stride=2) if fold else self.up(c2)
+            shift = self.spm.fc1.bias + self.up.bias if fold else None
+            return [fused.bn_tail(self.norm1, up, c1, x1, 4, shift), fused.bn_tail(self.norm2, c2, None, x2, 2),
                     fused.bn_tail(self.norm3, c3, None, x3, 1), self.norm4(c4)]
         c1 = self.up(c2) + c1
         return [self.norm1(c1), self.norm2(c2), self.norm3(c3), self.norm4(c4)]

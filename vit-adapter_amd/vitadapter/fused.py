@@ -13,7 +13,7 @@ import torch.nn.functional as F
 import _vah
 
 ENABLED = {'layer_norm': True, 'residual': True, 'residual_ln': True, 'dwconv': True, 'linear': True, 'bn_tail': True,
-           'bn_relu': True}
+           'bn_relu': True, 'bias_fold': True}
 for _k in os.environ.get('VAH_FUSED_DISABLE', '').split(','):      # e.g. VAH_FUSED_DISABLE=residual_ln,bn_tail (A/B runs)
     if _k:
         ENABLED[_k.strip()] = False
@@ -174,9 +174,6 @@ def _configure_gemm():
     if spec:
         parts = [int(v) for v in spec.split(',')]
         _vah.check(_vah.lib.vah_gemm_set_tuning(parts[0], parts[1] if len(parts) > 1 else 32), 'gemm_set_tuning')
-    path = os.environ.get('VAH_GEMM_TABLE', GEMM_TABLE)
-    if path and os.path.exists(path):
-        _vah.gemm_table_load(open(path).read())
     dump = os.environ.get('VAH_GEMM_TABLE_DUMP')
     if dump:
         import atexit
@@ -184,6 +181,16 @@ def _configure_gemm():
 
 
 _configure_gemm()
+_GEMM_TABLE_LOADED = False
+
+
+def _load_gemm_table():
+    """On the first GEMM (needs the GPU: the table is tied to the hipBLASLt build that is loaded)."""
+    global _GEMM_TABLE_LOADED
+    _GEMM_TABLE_LOADED = True
+    path = os.environ.get('VAH_GEMM_TABLE', GEMM_TABLE)
+    if path and os.path.exists(path):
+        _vah.gemm_table_load(open(path).read())
 
 
 def gemm_bf16(a, b, trans_a=False, trans_b=False, out_dtype=torch.bfloat16, bias=None):
@@ -197,6 +204,8 @@ def gemm_bf16(a, b, trans_a=False, trans_b=False, out_dtype=torch.bfloat16, bias
         return d
     if K == 0:
         return d.zero_()
+    if not _GEMM_TABLE_LOADED:
+        _load_gemm_table()
     ws_bytes = _GEMM_WS_BYTES
     if bias is None and K >= 4096:       # room for the fp32 partial products of a split-K run
         ws_bytes += min(64 * M * N * 4, 160 << 20)
@@ -462,8 +471,10 @@ class _BNTail(torch.autograd.Function):
     running statistics), normalise pass; SyncBatchNorm all-reduces the sums in between."""
 
     @staticmethod
-    def forward(ctx, a, b, x, weight, bias, norm, scale, relu, out_dtype):
+    def forward(ctx, a, b, x, weight, bias, shift, norm, scale, relu, out_dtype):
         N, C, H, W = a.shape
+        sh = shift.detach().float().contiguous() if shift is not None else None
+        shp = sh.data_ptr() if sh is not None else None
         a = a.contiguous()
         b = b.contiguous() if b is not None else None
         x = x.contiguous().float() if x is not None else None
@@ -479,7 +490,7 @@ class _BNTail(torch.autograd.Function):
             if training:
                 sums = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
                 ws = torch.empty(_vah.lib.vah_bn_tail_ws_floats(C), dtype=torch.float32, device=dev)
-                _vah.check(_vah.lib.vah_bn_tail_stats(*ops, sums.data_ptr(), ws.data_ptr(), st), 'bn_tail_stats')
+                _vah.check(_vah.lib.vah_bn_tail_stats(*ops, shp, sums.data_ptr(), ws.data_ptr(), st), 'bn_tail_stats')
                 sums[2 * C:].fill_(float(N * H * W))
                 if group is not None:
                     import torch.distributed as dist
@@ -502,16 +513,17 @@ class _BNTail(torch.autograd.Function):
             y = torch.empty((N, C, H, W), dtype=out_dtype, device=dev)
             _vah.check(_vah.lib.vah_bn_tail_apply(
                 *ops, mean.data_ptr(), rstd.data_ptr(), w.data_ptr() if w is not None else None,
-                bb.data_ptr() if bb is not None else None, int(relu), y.data_ptr(),
+                bb.data_ptr() if bb is not None else None, int(relu), shp, y.data_ptr(),
                 int(out_dtype == torch.bfloat16), st), 'bn_tail_apply')
-        ctx.save_for_backward(a, b, x, mean, rstd, w, bb, count)
+        ctx.save_for_backward(a, b, x, mean, rstd, w, bb, count, sh)
         ctx.meta = (scale, training, group, weight is not None, bias is not None, relu)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        a, b, x, mean, rstd, w, bb, count = ctx.saved_tensors
+        a, b, x, mean, rstd, w, bb, count, sh = ctx.saved_tensors
         scale, training, group, has_w, has_b, relu = ctx.meta
+        shp = sh.data_ptr() if sh is not None else None
         N, C, H, W = a.shape
         dy = dy.contiguous()
         if dy.dtype not in (torch.float32, torch.bfloat16):
@@ -526,7 +538,7 @@ class _BNTail(torch.autograd.Function):
         with torch.cuda.device(dev):
             sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
             ws = torch.empty(_vah.lib.vah_bn_tail_ws_floats(C), dtype=torch.float32, device=dev)
-            _vah.check(_vah.lib.vah_bn_tail_bwd_stats(*ops, mean.data_ptr(), rstd.data_ptr(), wp, bp, int(relu),
+            _vah.check(_vah.lib.vah_bn_tail_bwd_stats(*ops, mean.data_ptr(), rstd.data_ptr(), wp, bp, int(relu), shp,
                                                       dy.data_ptr(), dy_bf16, sums.data_ptr(), ws.data_ptr(), st),
                        'bn_tail_bwd_stats')
             local = sums.clone() if (training and group is not None) else sums      # dweight / dbias are per-rank sums
@@ -547,11 +559,16 @@ class _BNTail(torch.autograd.Function):
                 dx = torch.zeros_like(x) if scale > 1 else torch.empty_like(x)
             if da is not None or db is not None or dx is not None:
                 _vah.check(_vah.lib.vah_bn_tail_bwd_apply(
-                    *ops, mean.data_ptr(), rstd.data_ptr(), wp, bp, int(relu), dy.data_ptr(), dy_bf16,
+                    *ops, mean.data_ptr(), rstd.data_ptr(), wp, bp, int(relu), shp, dy.data_ptr(), dy_bf16,
                     means[:C].data_ptr(), means[C:].data_ptr(),
                     da.data_ptr() if da is not None else None, db.data_ptr() if db is not None else None,
                     dx.data_ptr() if dx is not None else None, st), 'bn_tail_bwd_apply')
-        return da, db, dx, dweight, dbias, None, None, None, None
+        dshift = None
+        if sh is not None and ctx.needs_input_grad[5]:
+            # d/d(shift) = sum of dt over the channel: BatchNorm in training removes channel constants
+            # (exactly 0); with running statistics it is gamma * rstd * sum(dy)
+            dshift = torch.zeros_like(sh) if training else (w if w is not None else 1.0) * rstd * local[:C]
+        return da, db, dx, dweight, dbias, dshift, None, None, None, None
 
 
 def _bn_fusable(norm, a):
@@ -561,6 +578,12 @@ def _bn_fusable(norm, a):
             and (not norm.training or a.shape[0] * a.shape[2] * a.shape[3] > 1)
             and (norm.training or norm.running_mean is not None)
             and (norm.weight is None or norm.weight.dtype == torch.float32))
+
+
+def tail_takes_conv_bias(norm, ref):
+    """True when bn_tail will run fused for inputs like ``ref``: the caller may then run the
+    convolutions that feed it WITHOUT bias and hand the biases to bn_tail as ``shift``."""
+    return ENABLED['bn_tail'] and ENABLED['bias_fold'] and _bn_fusable(norm, ref)
 
 
 def halve(x):
@@ -574,17 +597,20 @@ def halve(x):
     return F.interpolate(x, scale_factor=0.5, mode='bilinear', align_corners=False)
 
 
-def bn_tail(norm, a, b=None, x=None, scale=1):
+def bn_tail(norm, a, b=None, x=None, scale=1, shift=None):
     """``norm(a + b + F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=False))``
     for a (Sync)BatchNorm2d ``norm`` - the output tail of the backbone (ref vit_adapter.py:106-127);
-    ``b`` / ``x`` optional, ``scale == 1`` adds ``x`` as it is."""
+    ``b`` / ``x`` optional, ``scale == 1`` adds ``x`` as it is.  ``shift`` (C,): per-channel constant
+    added to the sum (biases of the convolutions that made ``a`` / ``b``, applied here for free)."""
     if (ENABLED['bn_tail'] and _bn_fusable(norm, a) and x is not None
             and (b is None or (b.shape == a.shape and b.dtype in (torch.bfloat16, torch.float32)))
             and scale in (1, 2, 4, 8) and a.shape[3] % (4 * scale) == 0 and a.shape[2] % scale == 0
             and tuple(x.shape) == (a.shape[0], a.shape[1], a.shape[2] // scale, a.shape[3] // scale)
             and x.dtype in (torch.bfloat16, torch.float32)):
-        return _BNTail.apply(a, b, x, norm.weight, norm.bias, norm, scale, False, torch.float32)
+        return _BNTail.apply(a, b, x, norm.weight, norm.bias, shift, norm, scale, False, torch.float32)
     t = a if b is None else a + b
+    if shift is not None:
+        t = t + shift.view(1, -1, 1, 1).to(t.dtype)
     if x is not None:
         t = t + (x if scale == 1 else F.interpolate(x, scale_factor=scale, mode='bilinear', align_corners=False))
     return norm(t)
@@ -599,5 +625,5 @@ def bn_relu(norm, a):
     the backward recomputes the ReLU mask from ``a``."""
     # the two-pass form pays from a few million elements on (below that MIOpen's single kernel wins)
     if ENABLED['bn_relu'] and _bn_fusable(norm, a) and a.shape[3] % 4 == 0 and a.numel() >= BN_RELU_MIN_NUMEL:
-        return _BNTail.apply(a, None, None, norm.weight, norm.bias, norm, 1, True, a.dtype)
+        return _BNTail.apply(a, None, None, norm.weight, norm.bias, None, norm, 1, True, a.dtype)
     return F.relu(norm(a))
