@@ -122,19 +122,26 @@ class Extractor(nn.Module):
             self.ffn_norm = norm_layer(dim)
             self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
 
-    def forward(self, query, reference_points, feat, spatial_shapes, level_start_index, H, W):
+    def forward(self, query, reference_points, feat, spatial_shapes, level_start_index, H, W, keep_feat=False):
+        """keep_feat: also return ``feat`` as it leaves the feat_norm node - a caller that goes on using
+        THAT tensor (x feeds further extractors and the next interaction) gets the sum of its gradients
+        formed inside the LayerNorm backward kernel instead of by a separate add per consumer."""
         def body(query, feat):
             query, qn = fused.layer_norm_keep(self.query_norm, query)
-            attn = self.attn(qn, reference_points, fused.layer_norm(self.feat_norm, feat), spatial_shapes,
-                             level_start_index, None)
+            feat, fn = fused.layer_norm_keep(self.feat_norm, feat, fan_out=True)
+            attn = self.attn(qn, reference_points, fn, spatial_shapes, level_start_index, None)
             if self.with_cffn:
                 query, qn = fused.residual_ln(query, attn, None, None, self.ffn_norm)
-                return fused.residual(query, self.ffn(qn, H, W), None, self.drop_path)
-            return fused.residual(query, attn)
+                out = fused.residual(query, self.ffn(qn, H, W), None, self.drop_path)
+            else:
+                out = fused.residual(query, attn)
+            return out, feat
 
         if self.with_cp and query.requires_grad:
-            return cp.checkpoint(body, query, feat, use_reentrant=False)
-        return body(query, feat)
+            out, feat = cp.checkpoint(body, query, feat, use_reentrant=False)
+        else:
+            out, feat = body(query, feat)
+        return (out, feat) if keep_feat else out
 
 
 class Injector(nn.Module):
@@ -150,16 +157,19 @@ class Injector(nn.Module):
                                  n_points=n_points, ratio=deform_ratio)
         self.gamma = nn.Parameter(init_values * torch.ones(dim), requires_grad=True)
 
-    def forward(self, query, reference_points, feat, spatial_shapes, level_start_index):
+    def forward(self, query, reference_points, feat, spatial_shapes, level_start_index, keep_feat=False):
+        """keep_feat: see Extractor.forward (here ``feat`` is c, which the extractor consumes next)."""
         def body(query, feat):
             query, qn = fused.layer_norm_keep(self.query_norm, query)
-            attn = self.attn(qn, reference_points, fused.layer_norm(self.feat_norm, feat), spatial_shapes,
-                             level_start_index, None)
-            return fused.residual(query, attn, self.gamma)
+            feat, fn = fused.layer_norm_keep(self.feat_norm, feat, fan_out=True)
+            attn = self.attn(qn, reference_points, fn, spatial_shapes, level_start_index, None)
+            return fused.residual(query, attn, self.gamma), feat
 
         if self.with_cp and query.requires_grad:
-            return cp.checkpoint(body, query, feat, use_reentrant=False)
-        return body(query, feat)
+            out, feat = cp.checkpoint(body, query, feat, use_reentrant=False)
+        else:
+            out, feat = body(query, feat)
+        return (out, feat) if keep_feat else out
 
 
 class InteractionBlock(nn.Module):
@@ -186,16 +196,17 @@ class InteractionBlock(nn.Module):
     def _extract(self, x, c, deform_inputs2, H, W):
         stages = [self.extractor] + (list(self.extra_extractors) if self.extra_extractors is not None else [])
         for stage in stages:
-            c = stage(query=c, reference_points=deform_inputs2[0], feat=x,
-                      spatial_shapes=deform_inputs2[1], level_start_index=deform_inputs2[2],
-                      H=H, W=W)
-        return c
+            c, x = stage(query=c, reference_points=deform_inputs2[0], feat=x,
+                         spatial_shapes=deform_inputs2[1], level_start_index=deform_inputs2[2],
+                         H=H, W=W, keep_feat=True)
+        return x, c
 
     def forward(self, x, c, blocks, deform_inputs1, deform_inputs2, H, W):
-        x = self.injector(query=x, reference_points=deform_inputs1[0], feat=c,
-                          spatial_shapes=deform_inputs1[1], level_start_index=deform_inputs1[2])
+        x, c = self.injector(query=x, reference_points=deform_inputs1[0], feat=c,
+                             spatial_shapes=deform_inputs1[1], level_start_index=deform_inputs1[2],
+                             keep_feat=True)
         x = run_blocks(blocks, x, H, W)
-        return x, self._extract(x, c, deform_inputs2, H, W)
+        return self._extract(x, c, deform_inputs2, H, W)
 
 
 class InteractionBlockWithCls(InteractionBlock):
@@ -203,12 +214,14 @@ class InteractionBlockWithCls(InteractionBlock):
     with_cls = True
 
     def forward(self, x, c, cls, blocks, deform_inputs1, deform_inputs2, H, W):
-        x = self.injector(query=x, reference_points=deform_inputs1[0], feat=c,
-                          spatial_shapes=deform_inputs1[1], level_start_index=deform_inputs1[2])
+        x, c = self.injector(query=x, reference_points=deform_inputs1[0], feat=c,
+                             spatial_shapes=deform_inputs1[1], level_start_index=deform_inputs1[2],
+                             keep_feat=True)
         x = torch.cat((cls, x), dim=1)
         x = run_blocks(blocks, x, H, W)
         cls, x = x[:, :1], x[:, 1:]
-        return x, self._extract(x, c, deform_inputs2, H, W), cls
+        x, c = self._extract(x, c, deform_inputs2, H, W)
+        return x, c, cls
 
 
 class SpatialPriorModule(nn.Module):

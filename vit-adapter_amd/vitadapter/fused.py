@@ -13,7 +13,7 @@ import torch.nn.functional as F
 import _vah
 
 ENABLED = {'layer_norm': True, 'residual': True, 'residual_ln': True, 'dwconv': True, 'linear': True, 'bn_tail': True,
-           'bn_relu': True, 'bias_fold': True}
+           'bn_relu': True, 'bias_fold': True, 'keep_feat': True}
 for _k in os.environ.get('VAH_FUSED_DISABLE', '').split(','):      # e.g. VAH_FUSED_DISABLE=residual_ln,bn_tail (A/B runs)
     if _k:
         ENABLED[_k.strip()] = False
@@ -95,9 +95,13 @@ def layer_norm(norm, x):
     return norm(x)
 
 
-def layer_norm_keep(norm, x):
+def layer_norm_keep(norm, x, fan_out=False):
     """``(x, norm(x))`` for the pattern ``x + branch(norm(x))``: use the returned ``x`` for the
-    residual update so both gradients of ``x`` are summed inside the LayerNorm backward kernel."""
+    residual update so both gradients of ``x`` are summed inside the LayerNorm backward kernel.
+    ``fan_out``: the kept tensor is not a residual of this sub-block but goes on to other consumers
+    (switchable for A/B runs: VAH_FUSED_DISABLE=keep_feat)."""
+    if fan_out and not ENABLED['keep_feat']:
+        return x, layer_norm(norm, x)
     if _ln_fusable(norm, x):
         return _LayerNormBF16.apply(x, norm.weight, norm.bias, norm.eps, True)
     return x, norm(x)
