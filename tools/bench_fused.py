@@ -54,6 +54,7 @@ def main():
             'ln_bwd': (10, lambda s: L.vah_layernorm_bwd_f32_bf16(p(s['x']), p(s['g']), p(w), p(s['mean']), p(s['rstd']), None, rows, C, p(s['y']), p(dw), p(db), p(ws), st)),
             'ln_bwd+gres': (14, lambda s: L.vah_layernorm_bwd_f32_bf16(p(s['x']), p(s['g']), p(w), p(s['mean']), p(s['rstd']), p(s['gres']), rows, C, p(s['y']), p(dw), p(db), p(ws), st)),
             'sr_fwd': (10, lambda s: L.vah_scale_residual_fwd(p(s['x']), p(s['z']), p(gamma), p(sc), B, rpb, C, p(s['y']), st)),
+            'sr_bwd (no gamma)': (6, lambda s: L.vah_scale_residual_bwd(p(s['gres']), p(s['z']), None, p(sc), B, rpb, C, p(s['dz']), None, None, st)),
             'sr_bwd': (8, lambda s: L.vah_scale_residual_bwd(p(s['gres']), p(s['z']), p(gamma), p(sc), B, rpb, C, p(s['dz']), p(dg), p(ws), st)),
             'res_ln_fwd': (12, lambda s: L.vah_residual_layernorm_fwd(p(s['x']), p(s['z']), p(gamma), p(sc), B, rpb, C, p(w), p(b), 1e-6, p(s['y']), p(s['h']), p(s['mean']), p(s['rstd']), st)),
             'res_ln_bwd': (18, lambda s: L.vah_residual_layernorm_bwd(p(s['x']), p(s['g']), p(w), p(s['mean']), p(s['rstd']), p(s['gres']), p(s['z']), p(gamma), p(sc), B, rpb, C, p(s['y']), p(s['dz']), p(dg), p(dw), p(db), p(ws), st)),

@@ -402,6 +402,23 @@ __global__ __launch_bounds__(256) void scale_residual_bwd_kernel(
     }
 }
 
+// dz = s[b] * g without a layer scale: no column reduction to carry, a flat streaming pass
+// (blockIdx.y = batch element, so no per-element division for s[b]).
+__global__ __launch_bounds__(256) void scale_only_bwd_kernel(const float *__restrict__ g, const float *__restrict__ s,
+                                                             int64_t vec_per_batch, __bf16 *__restrict__ dz) {
+    const float sb = s ? s[blockIdx.y] : 1.f;
+    const int64_t base = (int64_t)blockIdx.y * vec_per_batch;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < vec_per_batch; i += (int64_t)gridDim.x * 256) {
+        const float4 v = *reinterpret_cast<const float4 *>(g + 4 * (base + i));
+        bf16x4 o;
+        o[0] = (__bf16)(sb * v.x);
+        o[1] = (__bf16)(sb * v.y);
+        o[2] = (__bf16)(sb * v.z);
+        o[3] = (__bf16)(sb * v.w);
+        *reinterpret_cast<bf16x4 *>(dz + 4 * (base + i)) = o;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // depthwise 3x3 on the concatenated token maps
 // ---------------------------------------------------------------------------------------
@@ -721,9 +738,15 @@ int vah_scale_residual_bwd(const float *g, const void *z, const float *gamma, co
     }
     if (!g || !z || !dz || (dgamma && !ws)) return fail(VAH_E_NULL, "%s: null pointer", fn);
     if (((uintptr_t)g | (uintptr_t)gamma) % 16 || ((uintptr_t)z | (uintptr_t)dz) % 8) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    LaunchScope scope("scale_residual_bwd", rows * C * 8, st);
+    if (!gamma && batch <= 65535) {
+        const int64_t vpb = rows_per_batch * C / 4;
+        const unsigned gx = (unsigned)std::min<int64_t>((vpb + 1023) / 1024, 8192);
+        hipLaunchKernelGGL(scale_only_bwd_kernel, dim3(gx, (unsigned)batch), dim3(256), 0, st, g, s, vpb, (__bf16 *)dz);
+        return check_launch(fn);
+    }
     const int rpb = (int)((rows + kMaxParts - 1) / kMaxParts);
     const int64_t nblocks = (rows + rpb - 1) / rpb;
-    LaunchScope scope("scale_residual_bwd", rows * C * 8, st);
     hipLaunchKernelGGL(scale_residual_bwd_kernel, dim3((unsigned)nblocks), dim3(256), 0, st, g,
                        (const __bf16 *)z, gamma, s, rows, rows_per_batch, (int)C, rpb, (__bf16 *)dz,
                        dgamma ? ws : nullptr);
