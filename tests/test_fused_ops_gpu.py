@@ -403,3 +403,27 @@ def test_bn_relu_matches_reference_expression(N, C, H, W, dt, training, monkeypa
     _close(bn.bias.grad, ref_bn.bias.grad, 2e-2 if dt == torch.bfloat16 else 2e-4, 'dbias')
     _close(bn.running_mean, ref_bn.running_mean, 1e-5, 'running_mean')
     _close(bn.running_var, ref_bn.running_var, 1e-5, 'running_var')
+
+
+@pytest.mark.parametrize('B,C,H,W', [(2, 64, 8, 12), (1, 96, 6, 6), (3, 40, 4, 10)])
+def test_tokens_to_maps(B, C, H, W):
+    """fused.tokens_to_maps = the slice / transpose / reshape / contiguous lines of the pyramid assembly
+    (vit_adapter.py:113-119), forward bit-exact, backward into one gradient tensor (one map unused)."""
+    from vitadapter import fused
+    torch.manual_seed(10)
+    hw = [(2 * H, 2 * W), (H, W), (H // 2, W // 2)]
+    T = sum(h * w for h, w in hw)
+    c = torch.randn(B, T, C, device='cuda', requires_grad=True)
+    maps = fused.tokens_to_maps(c, hw)
+    assert type(maps[0].grad_fn).__name__ == '_TokensToMapsBackward'
+    c2 = c.detach().clone().requires_grad_(True)
+    ref, t0 = [], 0
+    for h, w in hw:
+        ref.append(c2[:, t0:t0 + h * w].transpose(1, 2).reshape(B, C, h, w).contiguous())
+        t0 += h * w
+    for m, r in zip(maps, ref):
+        assert torch.equal(m, r)
+    gs = [torch.randn_like(m) for m in maps]
+    torch.autograd.backward([maps[0], maps[2]], [gs[0], gs[2]])            # the middle map gets no gradient
+    torch.autograd.backward([ref[0], ref[2]], [gs[0], gs[2]])
+    assert torch.equal(c.grad, c2.grad)

@@ -84,11 +84,9 @@ class BEiTAdapter(BEiT):
         for i, layer in enumerate(self.interactions):
             lo, hi = self.interaction_indexes[i][0], self.interaction_indexes[i][-1]
             x, c, cls = layer(x, c, cls, self.blocks[lo:hi + 1], deform_inputs1, deform_inputs2, H, W)
-            outs.append(x.transpose(1, 2).reshape(bs, dim, H, W).contiguous())
+            outs.append(fused.tokens_to_maps(x, [(H, W)])[0])
 
-        c2 = c[:, :n2].transpose(1, 2).reshape(bs, dim, H * 2, W * 2).contiguous()
-        c3 = c[:, n2:n2 + n3].transpose(1, 2).reshape(bs, dim, H, W).contiguous()
-        c4 = c[:, n2 + n3:].transpose(1, 2).reshape(bs, dim, H // 2, W // 2).contiguous()
+        c2, c3, c4 = fused.tokens_to_maps(c, [(H * 2, W * 2), (H, W), (H // 2, W // 2)])
         if self.add_vit_feature:
             x1, x2, x3, x4 = outs
             c4 = c4 + fused.halve(x4)

@@ -136,16 +136,14 @@ class ViTAdapter(TIMMVisionTransformer):
             lo, hi = self.interaction_indexes[i][0], self.interaction_indexes[i][-1]
             x, c = layer(x, c, self.blocks[lo:hi + 1], deform_inputs1, deform_inputs2, H, W)
             if self.flavour == 'seg':
-                stage_maps.append(x.transpose(1, 2).reshape(bs, dim, H, W).contiguous())
+                stage_maps.append(fused.tokens_to_maps(x, [(H, W)])[0])
 
-        c2 = c[:, :n2].transpose(1, 2).reshape(bs, dim, H * 2, W * 2).contiguous()
-        c3 = c[:, n2:n2 + n3].transpose(1, 2).reshape(bs, dim, H, W).contiguous()
-        c4 = c[:, n2 + n3:].transpose(1, 2).reshape(bs, dim, H // 2, W // 2).contiguous()
+        c2, c3, c4 = fused.tokens_to_maps(c, [(H * 2, W * 2), (H, W), (H // 2, W // 2)])
         if self.add_vit_feature:
             if self.flavour == 'seg':
                 x1, x2, x3, x4 = stage_maps
             else:
-                x1 = x2 = x3 = x4 = x.transpose(1, 2).reshape(bs, dim, H, W).contiguous()
+                x1 = x2 = x3 = x4 = fused.tokens_to_maps(x, [(H, W)])[0]
             # f1 = norm1(up(c2) + c1 + interp(x1, 4)), f2 = norm2(c2 + interp(x2, 2)), f3 = norm3(c3 + x3):
             # sum, upsampling and batch norm in one pair of passes (csrc/tail_ops.hip); off the bf16
             # GPU path fused.bn_tail evaluates exactly the reference expression

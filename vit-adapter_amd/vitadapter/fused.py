@@ -13,7 +13,7 @@ import torch.nn.functional as F
 import _vah
 
 ENABLED = {'layer_norm': True, 'residual': True, 'residual_ln': True, 'dwconv': True, 'linear': True, 'bn_tail': True,
-           'bn_relu': True, 'bias_fold': True, 'keep_feat': True}
+           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True}
 for _k in os.environ.get('VAH_FUSED_DISABLE', '').split(','):      # e.g. VAH_FUSED_DISABLE=residual_ln,bn_tail (A/B runs)
     if _k:
         ENABLED[_k.strip()] = False
@@ -631,3 +631,63 @@ def bn_relu(norm, a):
     if ENABLED['bn_relu'] and _bn_fusable(norm, a) and a.shape[3] % 4 == 0 and a.numel() >= BN_RELU_MIN_NUMEL:
         return _BNTail.apply(a, None, None, norm.weight, norm.bias, None, norm, 1, True, a.dtype)
     return F.relu(norm(a))
+
+
+# ---------------------------------------------------------------------------------------
+# pyramid assembly: token sequences -> NCHW maps
+# ---------------------------------------------------------------------------------------
+class _TokensToMaps(torch.autograd.Function):
+    """(B, T, C) fp32 tokens holding consecutive maps of sizes ``hw`` -> one (B, C, h, w) map each.
+    Backward writes every map's gradient straight into its token range of ONE gradient tensor
+    (autograd's route: per map a transposed copy, a zero-filled full-size gradient, a slice copy and
+    an add)."""
+
+    @staticmethod
+    def forward(ctx, tokens, hw):
+        B, T, C = tokens.shape
+        tokens = tokens.contiguous()
+        outs, t0 = [], 0
+        with torch.cuda.device(tokens.device):
+            for h, w in hw:
+                o = torch.empty((B, C, h, w), dtype=torch.float32, device=tokens.device)
+                _vah.check(_vah.lib.vah_transpose_tokens_f32(tokens.data_ptr(), B, T, t0, h * w, C, o.data_ptr(), 1,
+                                                             _stream(tokens)), 'transpose_tokens')
+                outs.append(o)
+                t0 += h * w
+        ctx.hw, ctx.shape = hw, (B, T, C)
+        ctx.set_materialize_grads(False)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        B, T, C = ctx.shape
+        dev = next(g.device for g in grads if g is not None)
+        gt = torch.empty((B, T, C), dtype=torch.float32, device=dev)
+        t0 = 0
+        with torch.cuda.device(dev):
+            for (h, w), g in zip(ctx.hw, grads):
+                if g is None:
+                    gt[:, t0:t0 + h * w].zero_()
+                else:
+                    g = g.contiguous().float()
+                    _vah.check(_vah.lib.vah_transpose_tokens_f32(g.data_ptr(), B, T, t0, h * w, C, gt.data_ptr(), 0,
+                                                                 _stream(g)), 'transpose_tokens')
+                t0 += h * w
+        return gt, None
+
+
+def tokens_to_maps(tokens, hw):
+    """``[tokens[:, a:b].transpose(1, 2).reshape(B, C, h, w).contiguous() for the consecutive ranges]``
+    (vit_adapter.py:113-119); ``hw``: list of (h, w) whose areas add up to the token count."""
+    hw = tuple((int(h), int(w)) for h, w in hw)
+    assert sum(h * w for h, w in hw) == tokens.shape[1]
+    if (ENABLED['maps'] and tokens.is_cuda and tokens.dtype == torch.float32 and tokens.dim() == 3
+            and tokens.numel() > 0 and tokens.shape[0] <= 65535):
+        return list(_TokensToMaps.apply(tokens, hw))
+    outs, t0 = [], 0
+    B, _, C = tokens.shape
+    for h, w in hw:
+        outs.append(tokens[:, t0:t0 + h * w].transpose(1, 2).reshape(B, C, h, w).contiguous())
+        t0 += h * w
+    return outs
+
