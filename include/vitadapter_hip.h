@@ -298,11 +298,13 @@ int vah_bn_tail_bwd_apply(const void *a, int a_bf16, const void *b, int b_bf16, 
 int vah_bn_finalize_stats(const float *sums, int64_t C, float eps, float momentum, float *running_mean,
                           float *running_var, float *mean, float *rstd, void *stream);
 
-/* Pyramid assembly: token rows <-> NCHW planes (fp32).  to_planes != 0: dst (B, C, T) <- src (B, T_total, C)
- * rows [t0, t0 + T); else dst (B, T_total, C) rows [t0, t0 + T) <- src (B, C, T).  Replaces
- * c[:, a:b].transpose(1, 2).view(B, C, H, W).contiguous() (vit_adapter.py:113-119) and its backward. */
-int vah_transpose_tokens_f32(const float *src, int64_t B, int64_t T_total, int64_t t0, int64_t T, int64_t C,
-                             float *dst, int to_planes, void *stream);
+/* Token rows <-> NCHW planes.  to_planes != 0: dst (B, C, T) <- src (B, T_total, C) rows [t0, t0 + T);
+ * else dst (B, T_total, C) rows [t0, t0 + T) <- src (B, C, T) + vec[C] (vec optional).  Tokens fp32, planes
+ * fp32 or bf16.  Replaces c[:, a:b].transpose(1, 2).view(B, C, H, W).contiguous() of the pyramid assembly
+ * (vit_adapter.py:113-119), cat([fc_l(c_l).flatten(2).transpose(1, 2) + level_embed[l]]) of the SPM
+ * output (vit_adapter.py:94-97, adapter_modules.py:262-268) and their backward passes. */
+int vah_transpose_tokens(const void *src, int64_t B, int64_t T_total, int64_t t0, int64_t T, int64_t C, void *dst,
+                         int to_planes, int planes_bf16, const float *vec, void *stream);
 
 /* ---- bf16 GEMMs of the Linear layers (csrc/gemm.hip) ----------------------------------------
  * D (M x N, row-major, leading dimension ldd; bf16, or fp32 when d_is_f32) = op(A) op(B), bf16

@@ -427,3 +427,28 @@ def test_tokens_to_maps(B, C, H, W):
     torch.autograd.backward([maps[0], maps[2]], [gs[0], gs[2]])            # the middle map gets no gradient
     torch.autograd.backward([ref[0], ref[2]], [gs[0], gs[2]])
     assert torch.equal(c.grad, c2.grad)
+
+
+@pytest.mark.parametrize('dt', [torch.bfloat16, torch.float32])
+def test_maps_to_tokens(dt):
+    """fused.maps_to_tokens = cat([map.flatten(2).transpose(1, 2) + vec]) in fp32 (SPM output,
+    vit_adapter.py:94-97): forward and the gradients of maps and vectors."""
+    from vitadapter import fused
+    torch.manual_seed(11)
+    B, C = 2, 72
+    hw = [(8, 12), (4, 6), (2, 3)]
+    maps = [torch.randn(B, C, h, w, device='cuda').to(dt).requires_grad_(True) for h, w in hw]
+    vecs = [torch.randn(C, device='cuda', requires_grad=True) for _ in hw]
+    out = fused.maps_to_tokens(maps, vecs)
+    assert out.dtype == torch.float32 and type(out.grad_fn).__name__ == '_MapsToTokensBackward'
+    g = torch.randn_like(out)
+    out.backward(g)
+    maps2 = [m.detach().clone().requires_grad_(True) for m in maps]
+    vecs2 = [v.detach().clone().requires_grad_(True) for v in vecs]
+    ref = torch.cat([m.flatten(2).transpose(1, 2).float() + v for m, v in zip(maps2, vecs2)], dim=1)
+    ref.backward(g)
+    assert torch.equal(out, ref)
+    for m, m2 in zip(maps, maps2):
+        assert m.grad.dtype == dt and torch.equal(m.grad, m2.grad)
+    for v, v2 in zip(vecs, vecs2):
+        _close(v.grad, v2.grad, 1e-5, 'dvec')

@@ -338,35 +338,48 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float *__restric
     }
 }
 
-// (B, T_total, C) token rows [t0, t0 + T)  <->  (B, C, T) planes, fp32, through a 32 x 33 LDS tile
-// (both sides coalesced).  TO_PLANES: planes <- tokens; else tokens <- planes (the backward of it,
-// writing its own token range of a gradient buffer shared by several maps).
+// (B, T_total, C) fp32 token rows [t0, t0 + T)  <->  (B, C, T) planes (fp32 or bf16), through a
+// 32 x 33 LDS tile (both sides coalesced).  TO_PLANES: planes <- tokens; else tokens <- planes
+// (+ an optional per-channel vector: conv bias + level embedding of the SPM maps).
 template <bool TO_PLANES>
-__global__ __launch_bounds__(256) void transpose_tokens_kernel(const float *__restrict__ src, float *__restrict__ dst,
-                                                               int64_t T_total, int64_t t0, int T, int C) {
+__global__ __launch_bounds__(256) void transpose_tokens_kernel(const void *__restrict__ src, void *__restrict__ dst,
+                                                               int64_t T_total, int64_t t0, int T, int C,
+                                                               int planes_bf16, const float *__restrict__ vec) {
     __shared__ float tile[32][33];
     const int b = blockIdx.z;
     const int tt = blockIdx.x * 32, cc = blockIdx.y * 32;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;          // 32 x 8
-    const float *tok_base = (TO_PLANES ? src : dst) + ((int64_t)b * T_total + t0) * C;
-    float *tok_base_w = dst + ((int64_t)b * T_total + t0) * C;
+    const int64_t tok_off = ((int64_t)b * T_total + t0) * C;
     const int64_t plane_base = (int64_t)b * C * T;
     if (TO_PLANES) {
+        const float *tok = reinterpret_cast<const float *>(src) + tok_off;
 #pragma unroll
         for (int r = ly; r < 32; r += 8)                              // tile[token][channel], channel fastest
-            tile[r][lx] = (tt + r < T && cc + lx < C) ? tok_base[(int64_t)(tt + r) * C + cc + lx] : 0.f;
+            tile[r][lx] = (tt + r < T && cc + lx < C) ? tok[(int64_t)(tt + r) * C + cc + lx] : 0.f;
         __syncthreads();
 #pragma unroll
         for (int r = ly; r < 32; r += 8)                              // write plane rows: token fastest
-            if (cc + r < C && tt + lx < T) dst[plane_base + (int64_t)(cc + r) * T + tt + lx] = tile[lx][r];
+            if (cc + r < C && tt + lx < T) {
+                const int64_t o = plane_base + (int64_t)(cc + r) * T + tt + lx;
+                if (planes_bf16) reinterpret_cast<__bf16 *>(dst)[o] = (__bf16)tile[lx][r];
+                else reinterpret_cast<float *>(dst)[o] = tile[lx][r];
+            }
     } else {
 #pragma unroll
-        for (int r = ly; r < 32; r += 8)                              // tile[channel][token], token fastest
-            tile[r][lx] = (cc + r < C && tt + lx < T) ? src[plane_base + (int64_t)(cc + r) * T + tt + lx] : 0.f;
+        for (int r = ly; r < 32; r += 8) {                            // tile[channel][token], token fastest
+            float v = 0.f;
+            if (cc + r < C && tt + lx < T) {
+                const int64_t o = plane_base + (int64_t)(cc + r) * T + tt + lx;
+                v = planes_bf16 ? (float)reinterpret_cast<const __bf16 *>(src)[o] : reinterpret_cast<const float *>(src)[o];
+            }
+            tile[r][lx] = v;
+        }
         __syncthreads();
+        float *tok = reinterpret_cast<float *>(dst) + tok_off;
+        const float add = (vec && cc + lx < C) ? vec[cc + lx] : 0.f;
 #pragma unroll
         for (int r = ly; r < 32; r += 8)
-            if (tt + r < T && cc + lx < C) tok_base_w[(int64_t)(tt + r) * C + cc + lx] = tile[lx][r];
+            if (tt + r < T && cc + lx < C) tok[(int64_t)(tt + r) * C + cc + lx] = tile[lx][r] + add;
     }
 }
 
@@ -515,25 +528,30 @@ int vah_bn_finalize_stats(const float *sums, int64_t C, float eps, float momentu
 }
 
 // tokens -> planes (to_planes != 0): dst (B, C, T) <- src (B, T_total, C)[:, t0 : t0 + T, :];
-// planes -> tokens: dst (B, T_total, C)[:, t0 : t0 + T, :] <- src (B, C, T).  fp32.
+// planes -> tokens: dst (B, T_total, C)[:, t0 : t0 + T, :] <- src (B, C, T) (+ vec[C] if given).
+// Tokens are fp32; the planes fp32 or bf16 (planes_bf16).
 // Replaces  c[:, a:b].transpose(1, 2).view(B, C, H, W).contiguous()  of the pyramid assembly
-// (vit_adapter.py:113-119) and its backward (slice + transpose + zero-filled gradient + adds).
-int vah_transpose_tokens_f32(const float *src, int64_t B, int64_t T_total, int64_t t0, int64_t T, int64_t C,
-                             float *dst, int to_planes, void *stream) {
+// (vit_adapter.py:113-119) and  cat([fc_l(c_l).flatten(2).transpose(1, 2) + level_embed[l]])  of
+// vit_adapter.py:94-97 / adapter_modules.py:262-268, and their backward passes.
+int vah_transpose_tokens(const void *src, int64_t B, int64_t T_total, int64_t t0, int64_t T, int64_t C, void *dst,
+                         int to_planes, int planes_bf16, const float *vec, void *stream) {
     using namespace vah;
     clear_error();
-    const char *fn = "vah_transpose_tokens_f32";
+    const char *fn = "vah_transpose_tokens";
     if (B < 0 || T_total < 0 || t0 < 0 || T < 0 || t0 + T > T_total || C < 1 || B > 65535 || C > 65535 * 32 || T >= ((int64_t)1 << 31))
         return fail(VAH_E_SHAPE, "%s: bad dims", fn);
     if (B == 0 || T == 0) return VAH_OK;
     if (!src || !dst) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if (to_planes && vec) return fail(VAH_E_UNSUPPORTED, "%s: vec only applies to planes -> tokens", fn);
     const dim3 grid((unsigned)((T + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)B);
     hipStream_t st = (hipStream_t)stream;
-    LaunchScope scope("transpose_tokens", B * T * C * 8, st);
+    LaunchScope scope("transpose_tokens", B * T * C * (4 + (planes_bf16 ? 2 : 4)), st);
     if (to_planes)
-        hipLaunchKernelGGL(transpose_tokens_kernel<true>, grid, dim3(256), 0, st, src, dst, T_total, t0, (int)T, (int)C);
+        hipLaunchKernelGGL(transpose_tokens_kernel<true>, grid, dim3(256), 0, st, src, dst, T_total, t0, (int)T, (int)C,
+                           planes_bf16, vec);
     else
-        hipLaunchKernelGGL(transpose_tokens_kernel<false>, grid, dim3(256), 0, st, src, dst, T_total, t0, (int)T, (int)C);
+        hipLaunchKernelGGL(transpose_tokens_kernel<false>, grid, dim3(256), 0, st, src, dst, T_total, t0, (int)T, (int)C,
+                           planes_bf16, vec);
     return check_launch(fn);
 }
 

@@ -271,17 +271,22 @@ class SpatialPriorModule(nn.Module):
         # bias_free_c1: the 1x1 conv to embed_dim without its bias - the caller folds fc1.bias into the
         # BatchNorm tail (fused.bn_tail shift) instead of a 100 M-element bias-add pass
         c1 = F.conv2d(c1, self.fc1.weight, None) if self._bias_free_c1 else self.fc1(c1)
+        if self._raw_maps:
+            # the 1x1 convs without bias, still as maps: the caller adds bias + level embedding while
+            # it lays the tokens out (fused.maps_to_tokens)
+            return (c1, *(F.conv2d(c, f.weight, None) for f, c in ((self.fc2, c2), (self.fc3, c3), (self.fc4, c4))))
         tokens = [f(c).flatten(2).transpose(1, 2) for f, c in
                   ((self.fc2, c2), (self.fc3, c3), (self.fc4, c4))]
         return (c1, *tokens)
 
     _bias_free_c1 = False
+    _raw_maps = False
 
-    def forward(self, x, bias_free_c1=False):
-        self._bias_free_c1 = bool(bias_free_c1)
+    def forward(self, x, bias_free_c1=False, raw_maps=False):
+        self._bias_free_c1, self._raw_maps = bool(bias_free_c1), bool(raw_maps)
         try:
             if self.with_cp and x.requires_grad:
                 return cp.checkpoint(self._body, x, use_reentrant=False)
             return self._body(x)
         finally:
-            self._bias_free_c1 = False
+            self._bias_free_c1 = self._raw_maps = False

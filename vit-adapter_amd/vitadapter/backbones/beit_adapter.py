@@ -67,10 +67,16 @@ class BEiTAdapter(BEiT):
 
         # fused tail: the biases of spm.fc1 and self.up reach norm1 as a per-channel shift
         fold = self.add_vit_feature and fused.tail_takes_conv_bias(self.norm1, x)
-        c1, c2, c3, c4 = self.spm(x, bias_free_c1=fold)
-        c2, c3, c4 = self._add_level_embed(c2, c3, c4)
-        n2, n3 = c2.size(1), c3.size(1)
-        c = torch.cat([c2, c3, c4], dim=1)
+        if fused.ENABLED['maps'] and fused.ENABLED['maps_in'] and x.is_cuda:
+            # c2..c4 leave the SPM as bias-free maps; bias + level embedding are added while the token
+            # sequence is laid out (one pass per map instead of bias add, level add and cat)
+            c1, m2, m3, m4 = self.spm(x, bias_free_c1=fold, raw_maps=True)
+            c = fused.maps_to_tokens([m2, m3, m4], [f.bias + self.level_embed[i] for i, f in
+                                                   enumerate((self.spm.fc2, self.spm.fc3, self.spm.fc4))])
+        else:
+            c1, c2, c3, c4 = self.spm(x, bias_free_c1=fold)
+            c2, c3, c4 = self._add_level_embed(c2, c3, c4)
+            c = torch.cat([c2, c3, c4], dim=1)
 
         x, H, W = self.patch_embed(x)
         bs, n, dim = x.shape

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 import _vah
 
 ENABLED = {'layer_norm': True, 'residual': True, 'residual_ln': True, 'dwconv': True, 'linear': True, 'bn_tail': True,
-           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True}
+           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True, 'maps_in': True}
 for _k in os.environ.get('VAH_FUSED_DISABLE', '').split(','):      # e.g. VAH_FUSED_DISABLE=residual_ln,bn_tail (A/B runs)
     if _k:
         ENABLED[_k.strip()] = False
@@ -650,8 +650,8 @@ class _TokensToMaps(torch.autograd.Function):
         with torch.cuda.device(tokens.device):
             for h, w in hw:
                 o = torch.empty((B, C, h, w), dtype=torch.float32, device=tokens.device)
-                _vah.check(_vah.lib.vah_transpose_tokens_f32(tokens.data_ptr(), B, T, t0, h * w, C, o.data_ptr(), 1,
-                                                             _stream(tokens)), 'transpose_tokens')
+                _vah.check(_vah.lib.vah_transpose_tokens(tokens.data_ptr(), B, T, t0, h * w, C, o.data_ptr(), 1, 0, None,
+                                                         _stream(tokens)), 'transpose_tokens')
                 outs.append(o)
                 t0 += h * w
         ctx.hw, ctx.shape = hw, (B, T, C)
@@ -670,8 +670,8 @@ class _TokensToMaps(torch.autograd.Function):
                     gt[:, t0:t0 + h * w].zero_()
                 else:
                     g = g.contiguous().float()
-                    _vah.check(_vah.lib.vah_transpose_tokens_f32(g.data_ptr(), B, T, t0, h * w, C, gt.data_ptr(), 0,
-                                                                 _stream(g)), 'transpose_tokens')
+                    _vah.check(_vah.lib.vah_transpose_tokens(g.data_ptr(), B, T, t0, h * w, C, gt.data_ptr(), 0, 0, None,
+                                                             _stream(g)), 'transpose_tokens')
                 t0 += h * w
         return gt, None
 
@@ -690,4 +690,56 @@ def tokens_to_maps(tokens, hw):
         outs.append(tokens[:, t0:t0 + h * w].transpose(1, 2).reshape(B, C, h, w).contiguous())
         t0 += h * w
     return outs
+
+
+class _MapsToTokens(torch.autograd.Function):
+    """cat_l(map_l.flatten(2).transpose(1, 2) + vec_l) -> (B, sum T_l, C) fp32 in one pass per map; the
+    backward hands each map its gradient already transposed (bf16 like the map) and the vectors the
+    column sums of their token ranges."""
+
+    @staticmethod
+    def forward(ctx, *args):
+        n = len(args) // 2
+        maps, vecs = args[:n], args[n:]
+        B, C = maps[0].shape[:2]
+        hw = [(m.shape[2], m.shape[3]) for m in maps]
+        T = sum(h * w for h, w in hw)
+        dev = maps[0].device
+        out = torch.empty((B, T, C), dtype=torch.float32, device=dev)
+        t0 = 0
+        with torch.cuda.device(dev):
+            for m, v, (h, w) in zip(maps, vecs, hw):
+                m = m.contiguous()
+                vv = v.detach().float().contiguous() if v is not None else None
+                _vah.check(_vah.lib.vah_transpose_tokens(
+                    m.data_ptr(), B, T, t0, h * w, C, out.data_ptr(), 0, int(m.dtype == torch.bfloat16),
+                    vv.data_ptr() if vv is not None else None, _stream(m)), 'transpose_tokens')
+                t0 += h * w
+        ctx.meta = (hw, [m.dtype for m in maps], [v is not None for v in vecs], (B, T, C))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        hw, dts, has_vec, (B, T, C) = ctx.meta
+        g = g.contiguous().float()
+        gmaps, gvecs, t0 = [], [], 0
+        with torch.cuda.device(g.device):
+            for (h, w), dt, hv in zip(hw, dts, has_vec):
+                gm = torch.empty((B, C, h, w), dtype=dt, device=g.device)
+                _vah.check(_vah.lib.vah_transpose_tokens(g.data_ptr(), B, T, t0, h * w, C, gm.data_ptr(), 1,
+                                                         int(dt == torch.bfloat16), None, _stream(g)), 'transpose_tokens')
+                gmaps.append(gm)
+                gvecs.append(g[:, t0:t0 + h * w].sum((0, 1)) if hv else None)
+                t0 += h * w
+        return (*gmaps, *gvecs)
+
+
+def maps_to_tokens(maps, vecs):
+    """``torch.cat([m.flatten(2).transpose(1, 2) + v for m, v in zip(maps, vecs)], dim=1)`` in fp32
+    (the SPM's c2..c4 maps with their conv bias + level embedding, vit_adapter.py:94-97)."""
+    if (ENABLED['maps'] and maps[0].is_cuda and all(m.dim() == 4 and m.dtype in (torch.bfloat16, torch.float32)
+                                                    and m.shape[:2] == maps[0].shape[:2] for m in maps)
+            and maps[0].numel() > 0 and maps[0].shape[0] <= 65535):
+        return _MapsToTokens.apply(*maps, *vecs)
+    return torch.cat([m.flatten(2).transpose(1, 2).float() + (v if v is not None else 0.) for m, v in zip(maps, vecs)], dim=1)
 
