@@ -452,3 +452,37 @@ def test_maps_to_tokens(dt):
         assert m.grad.dtype == dt and torch.equal(m.grad, m2.grad)
     for v, v2 in zip(vecs, vecs2):
         _close(v.grad, v2.grad, 1e-5, 'dvec')
+
+
+def test_linear_pair_matches_two_linears():
+    """fused.linear_pair(a, b, x) = (a(x), b(x)) under bf16 autocast: forward and every gradient against the
+    two separate fused linears (same bf16 operands, fp32 accumulation)."""
+    from vitadapter import fused
+    torch.manual_seed(13)
+    a, b = torch.nn.Linear(768, 96).cuda(), torch.nn.Linear(768, 48).cuda()
+    x = torch.randn(2, 301, 768, device='cuda').to(torch.bfloat16).requires_grad_(True)
+    ga = torch.randn(2, 301, 96, device='cuda').to(torch.bfloat16)
+    gb = torch.randn(2, 301, 48, device='cuda').to(torch.bfloat16)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        ya, yb = fused.linear_pair(a, b, x)
+    assert type(ya.grad_fn).__name__ != 'AddmmBackward0' and ya.shape == (2, 301, 96) and yb.shape == (2, 301, 48)
+    torch.autograd.backward([ya, yb], [ga, gb])
+    got = [ya.detach().clone(), yb.detach().clone(), x.grad.clone(), a.weight.grad.clone(), a.bias.grad.clone(),
+           b.weight.grad.clone(), b.bias.grad.clone()]
+    x.grad = None
+    a.zero_grad()
+    b.zero_grad()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        ra, rb = fused.linear(a, x), fused.linear(b, x)
+    torch.autograd.backward([ra, rb], [ga, gb])
+    want = [ra, rb, x.grad, a.weight.grad, a.bias.grad, b.weight.grad, b.bias.grad]
+    for g, w, nm, tol in zip(got, want, ('ya', 'yb', 'dx', 'dWa', 'dba', 'dWb', 'dbb'),
+                             (1e-2, 1e-2, 2e-2, 1e-4, 1e-4, 1e-4, 1e-4)):
+        _close(g, w, tol, nm)
+    # the concatenated bf16 copy follows an in-place parameter update
+    with torch.no_grad():
+        b.weight.mul_(0.5)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        _, yb2 = fused.linear_pair(a, b, x)
+        rb2 = fused.linear(b, x)
+    _close(yb2, rb2, 1e-2, 'yb after update')

@@ -22,9 +22,13 @@ from ..functions import MSDeformAttnFunction, MSDeformAttnFusedFunction, fused_s
 
 try:        # fused nn.Linear (bf16 working copies, fp32 weight gradients) when the backbone package is there
     from vitadapter.fused import linear as _linear
+    from vitadapter.fused import linear_pair as _linear_pair
 except ImportError:                                                     # ops/ used on its own
     def _linear(lin, x):
         return lin(x)
+
+    def _linear_pair(lin_a, lin_b, x):
+        return lin_a(x), lin_b(x)
 
 _SCHEDULES = {}
 
@@ -115,8 +119,8 @@ class MSDeformAttn(nn.Module):
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, S, M, value.shape[-1] // M)
 
-        offsets = _linear(self.sampling_offsets, query).view(N, Lq, M, L, P, 2)
-        logits = _linear(self.attention_weights, query).view(N, Lq, M, L * P)
+        offsets, logits = _linear_pair(self.sampling_offsets, self.attention_weights, query)
+        offsets, logits = offsets.view(N, Lq, M, L, P, 2), logits.view(N, Lq, M, L * P)
         if fused_supported(value, offsets, logits, reference_points, L, P):
             # softmax + location arithmetic + gather in one kernel (csrc/msda_fused.hip)
             out = MSDeformAttnFusedFunction.apply(value, input_spatial_shapes, input_level_start_index,

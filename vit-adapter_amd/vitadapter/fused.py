@@ -13,7 +13,7 @@ import torch.nn.functional as F
 import _vah
 
 ENABLED = {'layer_norm': True, 'residual': True, 'residual_ln': True, 'dwconv': True, 'linear': True, 'bn_tail': True,
-           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True, 'maps_in': True}
+           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True, 'maps_in': True, 'linear_pair': True}
 for _k in os.environ.get('VAH_FUSED_DISABLE', '').split(','):      # e.g. VAH_FUSED_DISABLE=residual_ln,bn_tail (A/B runs)
     if _k:
         ENABLED[_k.strip()] = False
@@ -271,6 +271,92 @@ class _LinearBF16(torch.autograd.Function):
                 _vah.check(_vah.lib.vah_colsum_bf16(g2.data_ptr(), g2.shape[0], N, gb.data_ptr(),
                                                     ws.data_ptr(), _stream(g2)), 'colsum')
         return gx, gw, gb
+
+
+class _PairCopies:
+    """bf16 [Wa; Wb] (rows concatenated) and fp32 [ba; bb] of two Linear layers that read the same
+    input, rebuilt when either parameter has changed."""
+
+    def __init__(self):
+        self.entries = {}
+
+    def get(self, a, b):
+        key = (id(a.weight), id(b.weight))
+        ver = (a.weight._version, b.weight._version, a.bias._version, b.bias._version,
+               a.weight.data_ptr(), b.weight.data_ptr())
+        e = self.entries.get(key)
+        if e is None or e[0] != ver or e[1].device != a.weight.device:
+            with torch.no_grad():
+                w = torch.cat([a.weight.detach(), b.weight.detach()], 0).to(torch.bfloat16)
+                bias = torch.cat([a.bias.detach(), b.bias.detach()], 0).float()
+            e = (ver, w, bias)
+            if len(self.entries) > 1024:
+                self.entries.clear()
+            self.entries[key] = e
+        return e[1], e[2]
+
+
+PAIR_COPIES = _PairCopies()
+
+
+class _LinearPairBF16(torch.autograd.Function):
+    """(x Wa^T + ba, x Wb^T + bb) as ONE GEMM over the concatenated weights, and one input-gradient
+    GEMM, one weight-gradient GEMM and one column sum in the backward.  For MSDeformAttn's
+    sampling_offsets / attention_weights (ms_deform_attn.py:108-109): two skinny GEMMs (96 and 48
+    outputs per level) over the same 43008 x 768 query matrix plus the add autograd needs to sum the
+    two input gradients."""
+
+    @staticmethod
+    def forward(ctx, x, wa, ba, wb, bb, pair):
+        K = x.shape[-1]
+        x2 = x.reshape(-1, K)
+        if x2.dtype != torch.bfloat16:
+            x2 = x2.to(torch.bfloat16)
+        x2 = x2.contiguous()
+        w, bias = pair
+        y = gemm_bf16(x2, w, trans_b=True, bias=bias)
+        na = wa.shape[0]
+        ctx.save_for_backward(x2)
+        ctx.w, ctx.na, ctx.in_shape, ctx.in_dtype = w, na, x.shape, x.dtype
+        lead = x.shape[:-1]
+        return y[:, :na].contiguous().view(*lead, na), y[:, na:].contiguous().view(*lead, w.shape[0] - na)
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        (x2,) = ctx.saved_tensors
+        w, na = ctx.w, ctx.na
+        nb = w.shape[0] - na
+        R = x2.shape[0]
+        g = torch.empty((R, na + nb), dtype=torch.bfloat16, device=x2.device)
+        g[:, :na] = ga.reshape(R, na) if ga is not None else 0
+        g[:, na:] = gb.reshape(R, nb) if gb is not None else 0
+        gx = gw = gbias = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm_bf16(g, w).view(ctx.in_shape)
+            if gx.dtype != ctx.in_dtype:
+                gx = gx.to(ctx.in_dtype)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[3]:
+            gw = gemm_bf16(g, x2, trans_a=True, out_dtype=torch.float32)
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[4]:
+            gbias = torch.empty(na + nb, dtype=torch.float32, device=g.device)
+            ws = _scratch(na + nb, g.device)
+            with torch.cuda.device(g.device):
+                _vah.check(_vah.lib.vah_colsum_bf16(g.data_ptr(), R, na + nb, gbias.data_ptr(), ws.data_ptr(),
+                                                    _stream(g)), 'colsum')
+        return (gx, gw[:na] if gw is not None else None, gbias[:na] if gbias is not None else None,
+                gw[na:] if gw is not None else None, gbias[na:] if gbias is not None else None, None)
+
+
+def linear_pair(lin_a, lin_b, x):
+    """``(lin_a(x), lin_b(x))`` for two nn.Linear layers on the same input."""
+    wa, wb = lin_a.weight, lin_b.weight
+    if (ENABLED['linear'] and ENABLED['linear_pair'] and x.is_cuda and _bf16_autocast() and wa.dtype == torch.float32
+            and wb.dtype == torch.float32 and lin_a.bias is not None and lin_b.bias is not None
+            and x.dtype in (torch.bfloat16, torch.float32) and (wa.shape[0] + wb.shape[0]) % 8 == 0
+            and wa.shape[1] % 8 == 0 and wa.shape[1] == wb.shape[1] and x.numel() > 0
+            and type(lin_a) is torch.nn.Linear and type(lin_b) is torch.nn.Linear):
+        return _LinearPairBF16.apply(x, wa, lin_a.bias, wb, lin_b.bias, PAIR_COPIES.get(lin_a, lin_b))
+    return linear(lin_a, x), linear(lin_b, x)
 
 
 def linear(lin, x):
