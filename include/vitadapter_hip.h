@@ -256,6 +256,10 @@ int vah_residual_layernorm_bwd(const float *t, const void *gh_bf16, const float 
 /* out[c] = sum_r g[r][c] of a bf16 (rows, C) matrix, C % 8 == 0: the bias gradient of nn.Linear
  * (what autograd computes as grad_output.sum(0)); ws K = C. */
 int vah_colsum_bf16(const void *g_bf16, int64_t rows, int64_t C, float *out, float *ws, void *stream);
+/* fp32, over `batch` row blocks of a strided tensor: out[c] = sum_{b, r < rows} g[b * batch_stride + r * C + c]
+ * (the gradient of a per-channel vector added to a token range of a (B, T, C) tensor); C % 4 == 0. */
+int vah_colsum_f32(const float *g, int64_t batch, int64_t batch_stride, int64_t rows, int64_t C, float *out,
+                   float *ws, void *stream);
 
 /* ---- output tail: BatchNorm(a + b + bilinear_upsample_s(x)) (csrc/tail_ops.hip) ---------------
  * Reference: vit_adapter.py:106-127 (seg) / :101-120 (det):  c1 = up(c2) + c1;  c1 = c1 +

@@ -316,6 +316,54 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const __bf16 *__restri
     }
 }
 
+// fp32 variant over `batch` row blocks of a strided tensor (token range [t0, t0 + rows) of every batch
+// element of a (B, T, C) gradient): 32 column lanes x 4 floats, 8 row lanes; blockIdx.z = batch element.
+__global__ __launch_bounds__(256) void colsum_f32_kernel(const float *__restrict__ g, int64_t rows, int C,
+                                                         int64_t batch_stride, int rows_per_block,
+                                                         float *__restrict__ part) {
+    __shared__ float s_acc[8][128 + 4];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 128 + cl * 4;
+    const float *gb = g + (int64_t)blockIdx.z * batch_stride;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = min(rows, r0 + rows_per_block);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c0 < C) {
+        int64_t r = r0 + rl;
+        for (; r + 24 < r1; r += 32) {
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4 *>(gb + (r + 8 * u) * C + c0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc.x += v[u].x;
+                acc.y += v[u].y;
+                acc.z += v[u].z;
+                acc.w += v[u].w;
+            }
+        }
+        for (; r < r1; r += 8) {
+            const float4 v = *reinterpret_cast<const float4 *>(gb + r * C + c0);
+            acc.x += v.x;
+            acc.y += v.y;
+            acc.z += v.z;
+            acc.w += v.w;
+        }
+    }
+    s_acc[rl][cl * 4 + 0] = acc.x;
+    s_acc[rl][cl * 4 + 1] = acc.y;
+    s_acc[rl][cl * 4 + 2] = acc.z;
+    s_acc[rl][cl * 4 + 3] = acc.w;
+    __syncthreads();
+    const int c = blockIdx.x * 128 + threadIdx.x;
+    if (threadIdx.x < 128 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += s_acc[u][threadIdx.x];
+        part[((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * C + c] = t;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // y = x + s[b] * gamma[c] * z
 // ---------------------------------------------------------------------------------------
@@ -701,6 +749,37 @@ int vah_colsum_bf16(const void *g, int64_t rows, int64_t C, float *out, float *w
     hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)ctiles, (unsigned)parts), dim3(256), 0, st,
                        (const __bf16 *)g, rows, (int)C, (int)rpb, ws);
     hipLaunchKernelGGL(finalize_partials, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, st, ws, (int)parts,
+                       (int)C, out, (int)C, (float *)nullptr, 1 << 30, (float *)nullptr);
+    return check_launch(fn);
+}
+
+// out[c] = sum over b < batch, r < rows of g[b * batch_stride + r * C + c]  (fp32, C % 4 == 0): column sums
+// of a token range of a (B, T, C) tensor - the gradient of a per-channel vector added to that range.
+// ws: vah_reduce_ws_floats(C).
+int vah_colsum_f32(const float *g, int64_t batch, int64_t batch_stride, int64_t rows, int64_t C, float *out,
+                   float *ws, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_colsum_f32";
+    if (batch < 0 || rows < 0 || C < 4 || C % 4 || C > (1 << 20) || batch > 65535) return fail(VAH_E_SHAPE, "%s: bad dims", fn);
+    if (!out || !ws) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0 || batch == 0) {
+        (void)hipMemsetAsync(out, 0, C * 4, st);
+        return VAH_OK;
+    }
+    if (!g) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if ((uintptr_t)g % 16 || batch_stride % 4) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    const int ctiles = (int)((C + 127) / 128);
+    int64_t parts = std::min<int64_t>(kMaxParts / batch, std::max<int64_t>(1, 2048 / (ctiles * batch)));
+    parts = std::max<int64_t>(parts, 1);
+    if (parts * batch > kMaxParts) return fail(VAH_E_SHAPE, "%s: batch too large", fn);
+    int64_t rpb = std::max<int64_t>(32, (rows + parts - 1) / parts);
+    parts = (rows + rpb - 1) / rpb;
+    LaunchScope scope("colsum_f32", batch * rows * C * 4, st);
+    hipLaunchKernelGGL(colsum_f32_kernel, dim3((unsigned)ctiles, (unsigned)parts, (unsigned)batch), dim3(256), 0, st, g, rows,
+                       (int)C, batch_stride, (int)rpb, ws);
+    hipLaunchKernelGGL(finalize_partials, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, st, ws, (int)(parts * batch),
                        (int)C, out, (int)C, (float *)nullptr, 1 << 30, (float *)nullptr);
     return check_launch(fn);
 }

@@ -815,7 +815,15 @@ class _MapsToTokens(torch.autograd.Function):
                 _vah.check(_vah.lib.vah_transpose_tokens(g.data_ptr(), B, T, t0, h * w, C, gm.data_ptr(), 1,
                                                          int(dt == torch.bfloat16), None, _stream(g)), 'transpose_tokens')
                 gmaps.append(gm)
-                gvecs.append(g[:, t0:t0 + h * w].sum((0, 1)) if hv else None)
+                gv = None
+                if hv and C % 4 == 0:
+                    gv = torch.empty(C, dtype=torch.float32, device=g.device)
+                    ws = _scratch(C, g.device)
+                    _vah.check(_vah.lib.vah_colsum_f32(g[:, t0:].data_ptr(), B, T * C, h * w, C, gv.data_ptr(),
+                                                       ws.data_ptr(), _stream(g)), 'colsum_f32')
+                elif hv:
+                    gv = g[:, t0:t0 + h * w].sum((0, 1))
+                gvecs.append(gv)
                 t0 += h * w
         return (*gmaps, *gvecs)
 
