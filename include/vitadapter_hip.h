@@ -310,6 +310,13 @@ int vah_bn_finalize_stats(const float *sums, int64_t C, float eps, float momentu
 int vah_transpose_tokens(const void *src, int64_t B, int64_t T_total, int64_t t0, int64_t T, int64_t C, void *dst,
                          int to_planes, int planes_bf16, const float *vec, void *stream);
 
+/* MaxPool2d(kernel 3, stride 2, padding 1) of the SPM stem (adapter_modules.py:229-230) on bf16 NCHW, planes =
+ * N * C, output (H-1)/2+1 x (W-1)/2+1.  idx: one byte per output = window position (0..8, row-major) of the
+ * first maximum, the element torch's max_pool2d sends the gradient to; the backward gathers (no atomics). */
+int vah_maxpool3s2_fwd_bf16(const void *x, int64_t planes, int64_t H, int64_t W, void *y, void *idx, void *stream);
+int vah_maxpool3s2_bwd_bf16(const void *gy, const void *idx, int64_t planes, int64_t H, int64_t W, void *gx,
+                            void *stream);
+
 /* ---- bf16 GEMMs of the Linear layers (csrc/gemm.hip) ----------------------------------------
  * D (M x N, row-major, leading dimension ldd; bf16, or fp32 when d_is_f32) = op(A) op(B), bf16
  * operands, fp32 accumulation.  trans_a: A is stored (K x M) row-major and used transposed;

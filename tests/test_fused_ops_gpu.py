@@ -486,3 +486,22 @@ def test_linear_pair_matches_two_linears():
         _, yb2 = fused.linear_pair(a, b, x)
         rb2 = fused.linear(b, x)
     _close(yb2, rb2, 1e-2, 'yb after update')
+
+
+@pytest.mark.parametrize('N,C,H,W', [(2, 8, 32, 48), (1, 3, 17, 9), (2, 4, 64, 64)])
+def test_max_pool_3x3_s2_matches_torch(N, C, H, W):
+    """fused.max_pool = nn.MaxPool2d(3, 2, 1) on bf16 incl. the tie rule (inputs are post-ReLU: exact
+    zeros repeat, the first maximum in scan order takes the gradient) - bit-exact both ways."""
+    from vitadapter import fused
+    torch.manual_seed(14)
+    pool = torch.nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+    x = torch.relu(torch.randn(N, C, H, W, device='cuda')).to(torch.bfloat16).requires_grad_(True)
+    y = fused.max_pool(pool, x)
+    assert type(y.grad_fn).__name__ == '_MaxPool3s2Backward'
+    g = torch.randn_like(y)
+    y.backward(g)
+    x2 = x.detach().clone().requires_grad_(True)
+    yr = pool(x2)
+    yr.backward(g)
+    assert torch.equal(y, yr)
+    assert torch.equal(x.grad, x2.grad)

@@ -383,6 +383,93 @@ __global__ __launch_bounds__(256) void transpose_tokens_kernel(const void *__res
     }
 }
 
+// MaxPool2d(kernel 3, stride 2, padding 1) of the SPM stem (adapter_modules.py:229-230), bf16 NCHW.
+// Forward keeps the window position (0..8) of the FIRST maximum in row-major scan order - the element
+// torch's max_pool2d routes the gradient to - in one byte per output; backward is a gather: every
+// input pixel lies in at most 4 windows and takes their gradients where it is the recorded maximum
+// (torch's backward scatters with atomics: 222 us for the 2 x 64 x 512 x 512 stem map).
+__global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const __bf16 *__restrict__ x, int H, int W, int Ho, int Wo,
+                                                             __bf16 *__restrict__ y, unsigned char *__restrict__ idx) {
+    // block = 64 output columns x 4 output rows of one plane (blockIdx.z): no index divisions
+    const int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ox >= Wo || oy >= Ho) return;
+    const int64_t plane = blockIdx.z;
+    const __bf16 *xp = x + plane * H * W;
+    float best = -INFINITY;
+    int pos = 0;
+    bool any = false;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = 2 * oy - 1 + ky;
+        if (iy < 0 || iy >= H) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = 2 * ox - 1 + kx;
+            if (ix < 0 || ix >= W) continue;
+            const float v = (float)xp[(int64_t)iy * W + ix];
+            if (!any || v > best || v != v) {
+                best = v;
+                pos = ky * 3 + kx;
+                any = true;
+            }
+        }
+    }
+    const int64_t o = (plane * Ho + oy) * Wo + ox;
+    y[o] = (__bf16)best;
+    idx[o] = (unsigned char)pos;
+}
+
+// thread = 8 consecutive input columns of one input row (one 16-byte store); block = 64 x 4 such threads
+__global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const __bf16 *__restrict__ gy,
+                                                             const unsigned char *__restrict__ idx, int H, int W, int Ho,
+                                                             int Wo, __bf16 *__restrict__ gx) {
+    const int ix0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 8;
+    const int iy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (ix0 >= W || iy >= H) return;
+    const int64_t plane = blockIdx.z;
+    const __bf16 *gp = gy + plane * Ho * Wo;
+    const unsigned char *ip = idx + plane * Ho * Wo;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int oy0 = iy >> 1, oy1 = (iy + 1) >> 1;                  // the one or two window rows that contain iy
+    const int oxb = ix0 >> 1;                                       // windows oxb .. oxb + 4 touch these 8 columns
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int oy = a == 0 ? oy0 : oy1;
+        if ((a == 1 && oy1 == oy0) || oy >= Ho) continue;
+        const int ky3 = (iy - (2 * oy - 1)) * 3;
+        float g[5];
+        int p[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int ox = oxb + u;
+            const bool in = ox < Wo;
+            g[u] = in ? (float)gp[(int64_t)oy * Wo + ox] : 0.f;
+            p[u] = in ? (int)ip[(int64_t)oy * Wo + ox] : -1;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            // column ix0 + e lies in window (ix0 + e) >> 1 at kx = 1 (even e) or 2 (odd e), and in the next
+            // window at kx = 0 (odd e only); ix0 is a multiple of 8
+            const int u0 = e >> 1;
+            const int kx0 = (e & 1) ? 2 : 1;
+            if (p[u0] == ky3 + kx0) acc[e] += g[u0];
+            if (e & 1)
+                if (p[u0 + 1] == ky3 + 0) acc[e] += g[u0 + 1];
+        }
+    }
+    __bf16 *o = gx + (plane * H + iy) * (int64_t)W + ix0;
+    if (ix0 + 8 <= W && (W & 7) == 0) {
+        typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8_t;
+        bf16x8_t v;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (__bf16)acc[e];
+        *reinterpret_cast<bf16x8_t *>(o) = v;
+    } else {
+        for (int e = 0; e < 8 && ix0 + e < W; ++e) o[e] = (__bf16)acc[e];
+    }
+}
+
 int fill_operands(const char *fn, Operands &o, const void *a, int a_bf16, const void *b, int b_bf16, const float *x,
                   int scale, int64_t N, int64_t C, int64_t H, int64_t W) {
     if (N < 1 || C < 1 || H < 1 || W < 4 || W % 4 || W > kTilePx) return fail(VAH_E_SHAPE, "%s: bad shape", fn);
@@ -552,6 +639,43 @@ int vah_transpose_tokens(const void *src, int64_t B, int64_t T_total, int64_t t0
     else
         hipLaunchKernelGGL(transpose_tokens_kernel<false>, grid, dim3(256), 0, st, src, dst, T_total, t0, (int)T, (int)C,
                            planes_bf16, vec);
+    return check_launch(fn);
+}
+
+// MaxPool2d(3, stride 2, padding 1) on bf16 NCHW (planes = N * C): y, idx (1 byte per output: window position
+// of the first maximum) <- x;  backward: gx <- gy, idx (gather, no atomics).
+int vah_maxpool3s2_fwd_bf16(const void *x, int64_t planes, int64_t H, int64_t W, void *y, void *idx, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_maxpool3s2_fwd_bf16";
+    if (planes < 0 || H < 1 || W < 1 || H > (1 << 20) || W > (1 << 20)) return fail(VAH_E_SHAPE, "%s: bad dims", fn);
+    const int64_t Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, total = planes * Ho * Wo;
+    if (total == 0) return VAH_OK;
+    if (!x || !y || !idx) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    hipStream_t st = (hipStream_t)stream;
+    LaunchScope scope("maxpool_fwd", planes * (H * W * 2 + Ho * Wo * 3), st);
+    if (planes > 65535 || (Ho + 3) / 4 > 65535) return fail(VAH_E_SHAPE, "%s: too many planes / rows", fn);
+    hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3((unsigned)((Wo + 63) / 64), (unsigned)((Ho + 3) / 4), (unsigned)planes),
+                       dim3(256), 0, st, (const __bf16 *)x, (int)H, (int)W, (int)Ho, (int)Wo, (__bf16 *)y,
+                       (unsigned char *)idx);
+    return check_launch(fn);
+}
+
+int vah_maxpool3s2_bwd_bf16(const void *gy, const void *idx, int64_t planes, int64_t H, int64_t W, void *gx, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_maxpool3s2_bwd_bf16";
+    if (planes < 0 || H < 1 || W < 1 || H > (1 << 20) || W > (1 << 20)) return fail(VAH_E_SHAPE, "%s: bad dims", fn);
+    const int64_t Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1, total = planes * H * W;
+    if (total == 0) return VAH_OK;
+    if (!gy || !idx || !gx) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    hipStream_t st = (hipStream_t)stream;
+    LaunchScope scope("maxpool_bwd", planes * (H * W * 2 + Ho * Wo * 3), st);
+    if (planes > 65535 || (H + 3) / 4 > 65535) return fail(VAH_E_SHAPE, "%s: too many planes / rows", fn);
+    if ((uintptr_t)gx % 16) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((unsigned)((W + 511) / 512), (unsigned)((H + 3) / 4), (unsigned)planes),
+                       dim3(256), 0, st, (const __bf16 *)gy, (const unsigned char *)idx, (int)H, (int)W, (int)Ho, (int)Wo,
+                       (__bf16 *)gx);
     return check_launch(fn);
 }
 

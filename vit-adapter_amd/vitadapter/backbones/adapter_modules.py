@@ -258,6 +258,9 @@ class SpatialPriorModule(nn.Module):
                     and isinstance(mods[i + 1], nn.ReLU)):
                 x = fused.bn_relu(m, x)
                 i += 2
+            elif isinstance(m, nn.MaxPool2d):
+                x = fused.max_pool(m, x)
+                i += 1
             else:
                 x = m(x)
                 i += 1

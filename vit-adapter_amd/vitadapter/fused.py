@@ -13,7 +13,7 @@ import torch.nn.functional as F
 import _vah
 
 ENABLED = {'layer_norm': True, 'residual': True, 'residual_ln': True, 'dwconv': True, 'linear': True, 'bn_tail': True,
-           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True, 'maps_in': True, 'linear_pair': True}
+           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True, 'maps_in': True, 'linear_pair': True, 'maxpool': True}
 for _k in os.environ.get('VAH_FUSED_DISABLE', '').split(','):      # e.g. VAH_FUSED_DISABLE=residual_ln,bn_tail (A/B runs)
     if _k:
         ENABLED[_k.strip()] = False
@@ -836,4 +836,42 @@ def maps_to_tokens(maps, vecs):
             and maps[0].numel() > 0 and maps[0].shape[0] <= 65535):
         return _MapsToTokens.apply(*maps, *vecs)
     return torch.cat([m.flatten(2).transpose(1, 2).float() + (v if v is not None else 0.) for m, v in zip(maps, vecs)], dim=1)
+
+
+class _MaxPool3s2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        N, C, H, W = x.shape
+        x = x.contiguous()
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((N, C, Ho, Wo), dtype=torch.bfloat16, device=x.device)
+        idx = torch.empty((N, C, Ho, Wo), dtype=torch.uint8, device=x.device)
+        with torch.cuda.device(x.device):
+            _vah.check(_vah.lib.vah_maxpool3s2_fwd_bf16(x.data_ptr(), N * C, H, W, y.data_ptr(), idx.data_ptr(),
+                                                        _stream(x)), 'maxpool_fwd')
+        ctx.save_for_backward(idx)
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (idx,) = ctx.saved_tensors
+        N, C, H, W = ctx.shape
+        gy = gy.contiguous().to(torch.bfloat16)
+        gx = torch.empty((N, C, H, W), dtype=torch.bfloat16, device=gy.device)
+        with torch.cuda.device(gy.device):
+            _vah.check(_vah.lib.vah_maxpool3s2_bwd_bf16(gy.data_ptr(), idx.data_ptr(), N * C, H, W, gx.data_ptr(),
+                                                        _stream(gy)), 'maxpool_bwd')
+        return gx
+
+
+def max_pool(pool, x):
+    """``pool(x)`` for the SPM stem's nn.MaxPool2d(kernel_size=3, stride=2, padding=1)."""
+    def _is(v, k):
+        return v == k or v == (k, k)
+    if (ENABLED['maxpool'] and x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and x.numel() > 0
+            and isinstance(pool, torch.nn.MaxPool2d) and _is(pool.kernel_size, 3) and _is(pool.stride, 2)
+            and _is(pool.padding, 1) and _is(pool.dilation, 1) and not pool.ceil_mode and not pool.return_indices):
+        return _MaxPool3s2.apply(x)
+    return pool(x)
 
