@@ -505,3 +505,28 @@ def test_max_pool_3x3_s2_matches_torch(N, C, H, W):
     yr.backward(g)
     assert torch.equal(y, yr)
     assert torch.equal(x.grad, x2.grad)
+
+
+@pytest.mark.parametrize('B,Ci,Co,H,W', [(2, 64, 768, 32, 32), (1, 128, 96, 8, 24), (2, 256, 64, 4, 6)])
+def test_conv1x1_as_plane_gemms(B, Ci, Co, H, W):
+    """fused.conv1x1 = F.conv2d(x, w) for a 1x1 convolution under bf16 autocast (SPM fc1..fc4)."""
+    from vitadapter import fused
+    torch.manual_seed(15)
+    conv = torch.nn.Conv2d(Ci, Co, 1, bias=True).cuda()
+    x = torch.randn(B, Ci, H, W, device='cuda').to(torch.bfloat16).requires_grad_(True)
+    g = torch.randn(B, Co, H, W, device='cuda').to(torch.bfloat16)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        y = fused.conv1x1(conv, x)
+    assert type(y.grad_fn).__name__ == '_Conv1x1BF16Backward' and y.dtype == torch.bfloat16
+    y.backward(g)
+    # fp64 statement of the same products on the same bf16 operands (MIOpen's fp32 convolution is not a
+    # tight enough reference for the fp32 weight gradient)
+    xd, gd = x.detach().double().flatten(2), g.double().flatten(2)
+    wd = conv.weight.detach().to(torch.bfloat16).double().view(Co, Ci)
+    yr = torch.einsum('oi,bip->bop', wd, xd).view(B, Co, H, W)
+    dxr = torch.einsum('oi,bop->bip', wd, gd).view(B, Ci, H, W)
+    dwr = torch.einsum('bop,bip->oi', gd, xd).view(Co, Ci, 1, 1)
+    _close(y, yr, 1e-2, 'y')
+    _close(x.grad, dxr, 1e-2, 'dx')
+    _close(conv.weight.grad, dwr, 1e-5, 'dw')
+    assert conv.weight.grad.dtype == torch.float32 and conv.weight.grad.shape == conv.weight.shape

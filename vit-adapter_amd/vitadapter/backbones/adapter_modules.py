@@ -273,11 +273,11 @@ class SpatialPriorModule(nn.Module):
         c4 = self._run(self.conv4, c3)
         # bias_free_c1: the 1x1 conv to embed_dim without its bias - the caller folds fc1.bias into the
         # BatchNorm tail (fused.bn_tail shift) instead of a 100 M-element bias-add pass
-        c1 = F.conv2d(c1, self.fc1.weight, None) if self._bias_free_c1 else self.fc1(c1)
+        c1 = fused.conv1x1(self.fc1, c1) if self._bias_free_c1 else self.fc1(c1)
         if self._raw_maps:
             # the 1x1 convs without bias, still as maps: the caller adds bias + level embedding while
             # it lays the tokens out (fused.maps_to_tokens)
-            return (c1, *(F.conv2d(c, f.weight, None) for f, c in ((self.fc2, c2), (self.fc3, c3), (self.fc4, c4))))
+            return (c1, *(fused.conv1x1(f, c) for f, c in ((self.fc2, c2), (self.fc3, c3), (self.fc4, c4))))
         tokens = [f(c).flatten(2).transpose(1, 2) for f, c in
                   ((self.fc2, c2), (self.fc3, c3), (self.fc4, c4))]
         return (c1, *tokens)

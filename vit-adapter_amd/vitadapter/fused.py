@@ -13,7 +13,7 @@ import torch.nn.functional as F
 import _vah
 
 ENABLED = {'layer_norm': True, 'residual': True, 'residual_ln': True, 'dwconv': True, 'linear': True, 'bn_tail': True,
-           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True, 'maps_in': True, 'linear_pair': True, 'maxpool': True}
+           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True, 'maps_in': True, 'linear_pair': True, 'maxpool': True, 'conv1x1': True}
 for _k in os.environ.get('VAH_FUSED_DISABLE', '').split(','):      # e.g. VAH_FUSED_DISABLE=residual_ln,bn_tail (A/B runs)
     if _k:
         ENABLED[_k.strip()] = False
@@ -197,13 +197,17 @@ def _load_gemm_table():
         _vah.gemm_table_load(open(path).read())
 
 
-def gemm_bf16(a, b, trans_a=False, trans_b=False, out_dtype=torch.bfloat16, bias=None):
+def gemm_bf16(a, b, trans_a=False, trans_b=False, out_dtype=torch.bfloat16, bias=None, out=None):
     """op(a) @ op(b) for contiguous 2-D bf16 matrices on the tuned hipBLASLt dispatcher
     (csrc/gemm.hip); fp32 accumulation, bf16 or fp32 result."""
     M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
     N = b.shape[0] if trans_b else b.shape[1]
     assert (b.shape[1] if trans_b else b.shape[0]) == K and a.is_contiguous() and b.is_contiguous()
-    d = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    if out is not None:
+        assert out.shape == (M, N) and out.is_contiguous()
+        d, out_dtype = out, out.dtype
+    else:
+        d = torch.empty((M, N), dtype=out_dtype, device=a.device)
     if M == 0 or N == 0:
         return d
     if K == 0:
@@ -357,6 +361,56 @@ def linear_pair(lin_a, lin_b, x):
             and type(lin_a) is torch.nn.Linear and type(lin_b) is torch.nn.Linear):
         return _LinearPairBF16.apply(x, wa, lin_a.bias, wb, lin_b.bias, PAIR_COPIES.get(lin_a, lin_b))
     return linear(lin_a, x), linear(lin_b, x)
+
+
+class _Conv1x1BF16(torch.autograd.Function):
+    """1x1 convolution without bias on NCHW bf16 as plain GEMMs on the planes: out[b] (Co x HW) =
+    W (Co x Ci) x[b] (Ci x HW) - no NCHW <-> NHWC conversions around an implicit-GEMM kernel; the
+    weight gradient reduces over HW (65536 at the stride-4 map) with split-K."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        B, Ci, H, W = x.shape
+        Co = weight.shape[0]
+        x = x.contiguous()
+        wb = BF16_COPIES.get(weight).view(Co, Ci)
+        out = torch.empty((B, Co, H, W), dtype=torch.bfloat16, device=x.device)
+        for b in range(B):
+            gemm_bf16(wb, x[b].view(Ci, H * W), out=out[b].view(Co, H * W))
+        ctx.save_for_backward(x)
+        ctx.wb = wb
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        wb = ctx.wb
+        B, Ci, H, W = x.shape
+        Co = wb.shape[0]
+        g = g.contiguous().to(torch.bfloat16)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            for b in range(B):
+                gemm_bf16(wb, g[b].view(Co, H * W), trans_a=True, out=dx[b].view(Ci, H * W))
+        if ctx.needs_input_grad[1]:
+            for b in range(B):
+                part = gemm_bf16(g[b].view(Co, H * W), x[b].view(Ci, H * W), trans_b=True, out_dtype=torch.float32)
+                dw = part if dw is None else dw.add_(part)
+            dw = dw.view(Co, Ci, 1, 1)
+        return dx, dw
+
+
+def conv1x1(conv, x):
+    """``F.conv2d(x, conv.weight, None)`` for a 1x1 nn.Conv2d (the SPM's fc1..fc4 without their bias,
+    which the callers fold into the ops that follow)."""
+    w = conv.weight
+    if (ENABLED['conv1x1'] and ENABLED['linear'] and x.is_cuda and x.dtype == torch.bfloat16 and _bf16_autocast()
+            and x.dim() == 4 and w.dtype == torch.float32 and w.shape[2:] == (1, 1) and conv.stride == (1, 1)
+            and conv.padding == (0, 0) and conv.groups == 1 and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0
+            and (x.shape[2] * x.shape[3]) % 8 == 0 and x.numel() > 0):
+        return _Conv1x1BF16.apply(x, w)
+    return F.conv2d(x, w, None)
 
 
 def linear(lin, x):
