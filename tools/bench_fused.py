@@ -70,8 +70,6 @@ def main():
                 wd, bd = torch.randn(Cd, 9, device=d), torch.randn(Cd, device=d)
                 dwg = torch.empty(Cd * 10, device=d)
                 wsd = torch.empty(L.vah_reduce_ws_floats(10 * Cd), device=d)
-                for s_, (xx, yy) in zip(sets * 8, zip(xs, ys)):
-                    pass
                 dsets = [dict(x=a, y=b_) for a, b_ in zip(xs, ys)]
                 for name, bpe, fn in (
                         ('dwconv fwd (C/4)', 4, lambda s: L.vah_dwconv3x3_tokens_bf16(p(s['x']), p(wd), p(bd), B, Hd, Hd, Cd, 0, p(s['y']), st)),
