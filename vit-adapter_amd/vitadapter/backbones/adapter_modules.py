@@ -15,7 +15,6 @@ from functools import partial
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 import torch.utils.checkpoint as cp
 from ops.modules import MSDeformAttn
 

@@ -20,7 +20,6 @@ layers.  Parameter names (state_dict keys) are mmcv's: ``sampling_offsets``, ``a
 """
 import warnings
 
-import torch
 from ops.modules import MSDeformAttn
 from torch import nn
 
