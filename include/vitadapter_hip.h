@@ -253,6 +253,17 @@ int vah_residual_layernorm_bwd(const float *t, const void *gh_bf16, const float 
                                const float *rstd, const float *gt, const void *z_bf16, const float *gamma,
                                const float *sc, int64_t batch, int64_t rows_per_batch, int64_t C, float *dt,
                                void *dz_bf16, float *dgamma, float *dw, float *db, float *ws, void *stream);
+/* Two LayerNorms of the SAME fp32 rows with different affine parameters and equal eps (the adapter
+ * normalises c with injector.feat_norm and again, unchanged, with extractor.query_norm,
+ * adapter_modules.py:112-117,141-146): shared statistics, one read of x for both bf16 outputs; backward
+ * dx = gres + LN_a'(ga) + LN_b'(gb) in one pass (ga / gb / gres optional), dparams (4, C) = [dwa|dba|dwb|dbb].
+ * ws: vah_reduce_ws_floats(2 * C). */
+int vah_layernorm_dual_fwd(const float *x, const float *wa, const float *ba, const float *wb, const float *bb,
+                           int64_t rows, int64_t C, float eps, void *ya_bf16, void *yb_bf16, float *mean,
+                           float *rstd, void *stream);
+int vah_layernorm_dual_bwd(const float *x, const void *ga_bf16, const void *gb_bf16, const float *wa, const float *wb,
+                           const float *mean, const float *rstd, const float *gres, int64_t rows, int64_t C,
+                           float *dx, float *dparams, float *ws, void *stream);
 /* out[c] = sum_r g[r][c] of a bf16 (rows, C) matrix, C % 8 == 0: the bias gradient of nn.Linear
  * (what autograd computes as grad_output.sum(0)); ws K = C. */
 int vah_colsum_bf16(const void *g_bf16, int64_t rows, int64_t C, float *out, float *ws, void *stream);

@@ -530,3 +530,44 @@ def test_conv1x1_as_plane_gemms(B, Ci, Co, H, W):
     _close(x.grad, dxr, 1e-2, 'dx')
     _close(conv.weight.grad, dwr, 1e-5, 'dw')
     assert conv.weight.grad.dtype == torch.float32 and conv.weight.grad.shape == conv.weight.shape
+
+
+@pytest.mark.parametrize('shape', [(2, 150, 768), (1, 77, 192), (3, 33, 1024)])
+def test_layer_norm_dual_keep(shape):
+    """fused.layer_norm_dual_keep = (x, norm_a(x), norm_b(x)) with shared statistics; backward = residual
+    gradient + both LayerNorm gradients in one pass; also with one of the three outputs unused."""
+    from vitadapter import fused
+    torch.manual_seed(16)
+    C = shape[-1]
+    na, nb = torch.nn.LayerNorm(C, eps=1e-6).cuda(), torch.nn.LayerNorm(C, eps=1e-6).cuda()
+    with torch.no_grad():
+        for n in (na, nb):
+            n.weight.normal_(1, 0.3)
+            n.bias.normal_(0, 0.3)
+    x = (torch.randn(shape, device='cuda') * 1.7 + 0.4).requires_grad_(True)
+    gr = torch.randn(shape, device='cuda')
+    ga = torch.randn(shape, device='cuda').to(torch.bfloat16)
+    gb = torch.randn(shape, device='cuda').to(torch.bfloat16)
+    for use in ((True, True, True), (False, True, True), (True, True, False)):
+        x.grad = None
+        na.zero_grad()
+        nb.zero_grad()
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            xk, ya, yb = fused.layer_norm_dual_keep(na, nb, x * 1.0)
+        assert type(ya.grad_fn).__name__ == '_LayerNormDualBF16Backward'
+        outs = [t for t, u in zip((xk, ya, yb), use) if u]
+        grads = [g for g, u in zip((gr, ga, gb), use) if u]
+        torch.autograd.backward(outs, grads)
+        got = [x.grad.clone(), na.weight.grad.clone(), na.bias.grad.clone()] + \
+            ([nb.weight.grad.clone(), nb.bias.grad.clone()] if use[2] else [])
+        x.grad = None
+        na.zero_grad()
+        nb.zero_grad()
+        xr = x * 1.0
+        ref_outs = [t for t, u in zip((xr, na(xr), nb(xr)), use) if u]
+        torch.autograd.backward(ref_outs, [g.float() for g in grads])
+        want = [x.grad, na.weight.grad, na.bias.grad] + ([nb.weight.grad, nb.bias.grad] if use[2] else [])
+        for g, w, nm, tol in zip(got, want, ('dx', 'dwa', 'dba', 'dwb', 'dbb'), (1e-4, 1e-3, 1e-3, 1e-3, 1e-3)):
+            _close(g, w, tol, nm)
+        if use[1]:
+            _close(ya, na(x), 1e-2, 'ya')

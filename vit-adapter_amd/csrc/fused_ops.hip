@@ -275,6 +275,145 @@ __global__ __launch_bounds__(64 * kWaves) void ln_bwd_kernel(const float *__rest
 }
 
 // ---------------------------------------------------------------------------------------
+// Two LayerNorms of the SAME rows with different affine parameters (equal eps): the adapter
+// normalises c with injector.feat_norm and, unchanged, again with extractor.query_norm
+// (adapter_modules.py:112-117, 141-146), and x with extractor.feat_norm and the next injector's
+// query_norm.  Statistics and xhat are shared: one read of x for both outputs, and one backward pass
+//   dx = gres + rstd * (gw - mean(gw) - xhat * mean(gw * xhat)),   gw = ga * wa + gb * wb
+// instead of two chained passes over 132 MB rows.
+// ---------------------------------------------------------------------------------------
+template <int kMaxVec>
+__global__ __launch_bounds__(256) void ln_dual_fwd_kernel(const float *__restrict__ x, const float *__restrict__ wa,
+                                                          const float *__restrict__ ba, const float *__restrict__ wb,
+                                                          const float *__restrict__ bb, int64_t rows, int C, float eps,
+                                                          __bf16 *__restrict__ ya, __bf16 *__restrict__ yb,
+                                                          float *__restrict__ mean, float *__restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = C >> 2;
+    const float *xr = x + row * C;
+    float4 v[kMaxVec];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxVec; ++j) {
+        const int i = lane + 64 * j;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nvec) v[j] = *reinterpret_cast<const float4 *>(xr + 4 * i);
+        s += v[j].x + v[j].y + v[j].z + v[j].w;
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < kMaxVec; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nvec) {
+            const float a = v[j].x - mu, b2 = v[j].y - mu, c = v[j].z - mu, d = v[j].w - mu;
+            q += a * a + b2 * b2 + c * c + d * d;
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int j = 0; j < kMaxVec; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nvec) {
+            const float4 xh = make_float4((v[j].x - mu) * rs, (v[j].y - mu) * rs, (v[j].z - mu) * rs, (v[j].w - mu) * rs);
+            const float4 w1 = *reinterpret_cast<const float4 *>(wa + 4 * i), b1 = *reinterpret_cast<const float4 *>(ba + 4 * i);
+            const float4 w2 = *reinterpret_cast<const float4 *>(wb + 4 * i), b2 = *reinterpret_cast<const float4 *>(bb + 4 * i);
+            bf16x4 o1, o2;
+            o1[0] = (__bf16)(xh.x * w1.x + b1.x);
+            o1[1] = (__bf16)(xh.y * w1.y + b1.y);
+            o1[2] = (__bf16)(xh.z * w1.z + b1.z);
+            o1[3] = (__bf16)(xh.w * w1.w + b1.w);
+            o2[0] = (__bf16)(xh.x * w2.x + b2.x);
+            o2[1] = (__bf16)(xh.y * w2.y + b2.y);
+            o2[2] = (__bf16)(xh.z * w2.z + b2.z);
+            o2[3] = (__bf16)(xh.w * w2.w + b2.w);
+            *reinterpret_cast<bf16x4 *>(ya + row * C + 4 * i) = o1;
+            *reinterpret_cast<bf16x4 *>(yb + row * C + 4 * i) = o2;
+        }
+    }
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs;
+    }
+}
+
+// partial row: [dwa | dba | dwb | dbb]
+template <int kMaxVec>
+__global__ __launch_bounds__(256) void ln_dual_bwd_kernel(const float *__restrict__ x, const __bf16 *__restrict__ ga,
+                                                          const __bf16 *__restrict__ gb, const float *__restrict__ wa,
+                                                          const float *__restrict__ wb, const float *__restrict__ mean,
+                                                          const float *__restrict__ rstd, const float *__restrict__ gres,
+                                                          int64_t rows, int C, float *__restrict__ dx,
+                                                          float *__restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float s_red[];      // [4][4C]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nvec = C >> 2;
+    float4 w1[kMaxVec], w2[kMaxVec], aw1[kMaxVec], ab1[kMaxVec], aw2[kMaxVec], ab2[kMaxVec];
+#pragma unroll
+    for (int j = 0; j < kMaxVec; ++j) {
+        const int i = lane + 64 * j;
+        w1[j] = w2[j] = aw1[j] = ab1[j] = aw2[j] = ab2[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nvec) {
+            w1[j] = *reinterpret_cast<const float4 *>(wa + 4 * i);
+            w2[j] = *reinterpret_cast<const float4 *>(wb + 4 * i);
+        }
+    }
+    const float invC = 1.f / (float)C;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wv; row < rows; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float4 xh[kMaxVec], gw[kMaxVec], rv[kMaxVec];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < kMaxVec; ++j) {
+            const int i = lane + 64 * j;
+            xh[j] = gw[j] = rv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < nvec) {
+                const float4 xv = *reinterpret_cast<const float4 *>(x + row * C + 4 * i);
+                const bf16x4 g1 = ga ? *reinterpret_cast<const bf16x4 *>(ga + row * C + 4 * i) : bf16x4{};
+                const bf16x4 g2 = gb ? *reinterpret_cast<const bf16x4 *>(gb + row * C + 4 * i) : bf16x4{};
+                if (gres) rv[j] = *reinterpret_cast<const float4 *>(gres + row * C + 4 * i);
+                xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                const float a0 = (float)g1[0], a1 = (float)g1[1], a2 = (float)g1[2], a3 = (float)g1[3];
+                const float b0 = (float)g2[0], b1 = (float)g2[1], b2 = (float)g2[2], b3 = (float)g2[3];
+                gw[j] = make_float4(a0 * w1[j].x + b0 * w2[j].x, a1 * w1[j].y + b1 * w2[j].y, a2 * w1[j].z + b2 * w2[j].z,
+                                    a3 * w1[j].w + b3 * w2[j].w);
+                s1 += gw[j].x + gw[j].y + gw[j].z + gw[j].w;
+                s2 += gw[j].x * xh[j].x + gw[j].y * xh[j].y + gw[j].z * xh[j].z + gw[j].w * xh[j].w;
+                aw1[j].x += a0 * xh[j].x, aw1[j].y += a1 * xh[j].y, aw1[j].z += a2 * xh[j].z, aw1[j].w += a3 * xh[j].w;
+                ab1[j].x += a0, ab1[j].y += a1, ab1[j].z += a2, ab1[j].w += a3;
+                aw2[j].x += b0 * xh[j].x, aw2[j].y += b1 * xh[j].y, aw2[j].z += b2 * xh[j].z, aw2[j].w += b3 * xh[j].w;
+                ab2[j].x += b0, ab2[j].y += b1, ab2[j].z += b2, ab2[j].w += b3;
+            }
+        }
+        const float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
+#pragma unroll
+        for (int j = 0; j < kMaxVec; ++j) {
+            const int i = lane + 64 * j;
+            if (i < nvec)
+                *reinterpret_cast<float4 *>(dx + row * C + 4 * i) =
+                    make_float4(rv[j].x + rs * (gw[j].x - m1 - xh[j].x * m2), rv[j].y + rs * (gw[j].y - m1 - xh[j].y * m2),
+                                rv[j].z + rs * (gw[j].z - m1 - xh[j].z * m2), rv[j].w + rs * (gw[j].w - m1 - xh[j].w * m2));
+        }
+    }
+    const int K = 4 * C;
+#pragma unroll
+    for (int j = 0; j < kMaxVec; ++j) {
+        const int i = lane + 64 * j;
+        if (i < nvec) {
+            *reinterpret_cast<float4 *>(s_red + wv * K + 4 * i) = aw1[j];
+            *reinterpret_cast<float4 *>(s_red + wv * K + C + 4 * i) = ab1[j];
+            *reinterpret_cast<float4 *>(s_red + wv * K + 2 * C + 4 * i) = aw2[j];
+            *reinterpret_cast<float4 *>(s_red + wv * K + 3 * C + 4 * i) = ab2[j];
+        }
+    }
+    __syncthreads();
+    float *pr = part + (int64_t)blockIdx.x * K;
+    for (int k = threadIdx.x; k < K; k += 256) pr[k] = (s_red[k] + s_red[K + k]) + (s_red[2 * K + k] + s_red[3 * K + k]);
+}
+
+// ---------------------------------------------------------------------------------------
 // Column sums of a bf16 [rows, C] matrix (bias gradient of a Linear).  Workgroup = 32 column lanes
 // (8 bf16 = 16 bytes each: 256 columns) x 8 row lanes over a strip of rows; one partial row each.
 // ---------------------------------------------------------------------------------------
@@ -724,6 +863,65 @@ int vah_residual_layernorm_bwd(const float *t, const void *gh, const float *w, c
     return ln_bwd_launch(fn, t, gh, w, mean, rstd, gt, batch * rows_per_batch, C,
                          ResidualIn{(const __bf16 *)z, gamma, sc, std::max<int64_t>(rows_per_batch, 1), nullptr}, dz, dt, dw,
                          db, dgamma, ws, stream);
+}
+
+// Two LayerNorms of the same fp32 rows (shared statistics, equal eps): ya, yb bf16.
+int vah_layernorm_dual_fwd(const float *x, const float *wa, const float *ba, const float *wb, const float *bb,
+                           int64_t rows, int64_t C, float eps, void *ya, void *yb, float *mean, float *rstd,
+                           void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_layernorm_dual_fwd";
+    if (rows < 0 || C < 4 || C % 4 || C > 64 * 4 * 4) return fail(VAH_E_SHAPE, "%s: C=%lld unsupported", fn, (long long)C);
+    if (rows == 0) return VAH_OK;
+    if (!x || !wa || !ba || !wb || !bb || !ya || !yb || !mean || !rstd) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if (((uintptr_t)x | (uintptr_t)wa | (uintptr_t)ba | (uintptr_t)wb | (uintptr_t)bb) % 16 || ((uintptr_t)ya | (uintptr_t)yb) % 8)
+        return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    hipStream_t st = (hipStream_t)stream;
+    LaunchScope scope("layernorm_dual_fwd", rows * C * 8, st);
+#define VAH_LND_FWD(NV)                                                                                            \
+    hipLaunchKernelGGL(ln_dual_fwd_kernel<NV>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, wa, ba, wb, bb, rows, \
+                       (int)C, eps, (__bf16 *)ya, (__bf16 *)yb, mean, rstd)
+    if (C <= 256) VAH_LND_FWD(1);
+    else if (C <= 512) VAH_LND_FWD(2);
+    else VAH_LND_FWD(4);
+#undef VAH_LND_FWD
+    return check_launch(fn);
+}
+
+// Backward of both: dx = gres + LN_a'(ga) + LN_b'(gb) in one pass (ga / gb / gres optional);
+// dparams (4, C) = [dwa | dba | dwb | dbb].  ws: vah_reduce_ws_floats(2 * C).
+int vah_layernorm_dual_bwd(const float *x, const void *ga, const void *gb, const float *wa, const float *wb,
+                           const float *mean, const float *rstd, const float *gres, int64_t rows, int64_t C, float *dx,
+                           float *dparams, float *ws, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_layernorm_dual_bwd";
+    if (rows < 0 || C < 4 || C % 4 || C > 64 * 4 * 4) return fail(VAH_E_SHAPE, "%s: C=%lld unsupported", fn, (long long)C);
+    if (!dparams || !ws) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) {
+        (void)hipMemsetAsync(dparams, 0, 4 * C * 4, st);
+        return VAH_OK;
+    }
+    if (!x || !wa || !wb || !mean || !rstd || !dx) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if (((uintptr_t)x | (uintptr_t)wa | (uintptr_t)wb | (uintptr_t)dx | (uintptr_t)gres) % 16 || ((uintptr_t)ga | (uintptr_t)gb) % 8)
+        return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    const int64_t nblocks = std::min<int64_t>((rows + 3) / 4, kMaxParts / 2);       // the scratch holds kMaxParts * 2C floats
+    const size_t smem = (size_t)4 * 4 * C * sizeof(float);
+    if (smem > 64 * 1024) return fail(VAH_E_SHAPE, "%s: C too large", fn);
+    LaunchScope scope("layernorm_dual_bwd", rows * C * 16, st);
+#define VAH_LND_BWD(NV)                                                                                              \
+    hipLaunchKernelGGL(ln_dual_bwd_kernel<NV>, dim3((unsigned)nblocks), dim3(256), smem, st, x, (const __bf16 *)ga,   \
+                       (const __bf16 *)gb, wa, wb, mean, rstd, gres, rows, (int)C, dx, ws)
+    if (C <= 256) VAH_LND_BWD(1);
+    else if (C <= 512) VAH_LND_BWD(2);
+    else VAH_LND_BWD(4);
+#undef VAH_LND_BWD
+    // partial row = [dwa | dba | dwb | dbb] = the layout of dparams
+    hipLaunchKernelGGL(finalize_partials, dim3((unsigned)((4 * C + 31) / 32)), dim3(256), 0, st, ws, (int)nblocks, (int)(4 * C),
+                       dparams, (int)(4 * C), (float *)nullptr, 1 << 30, (float *)nullptr);
+    return check_launch(fn);
 }
 
 // out[c] = sum_r g[r][c] for a bf16 [rows, C] matrix, C % 8 == 0; ws: vah_reduce_ws_floats(C).

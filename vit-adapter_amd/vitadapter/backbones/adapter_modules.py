@@ -121,12 +121,16 @@ class Extractor(nn.Module):
             self.ffn_norm = norm_layer(dim)
             self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
 
-    def forward(self, query, reference_points, feat, spatial_shapes, level_start_index, H, W, keep_feat=False):
+    def forward(self, query, reference_points, feat, spatial_shapes, level_start_index, H, W, keep_feat=False,
+                query_normed=None):
         """keep_feat: also return ``feat`` as it leaves the feat_norm node - a caller that goes on using
         THAT tensor (x feeds further extractors and the next interaction) gets the sum of its gradients
-        formed inside the LayerNorm backward kernel instead of by a separate add per consumer."""
-        def body(query, feat):
-            query, qn = fused.layer_norm_keep(self.query_norm, query)
+        formed inside the LayerNorm backward kernel instead of by a separate add per consumer.
+        query_normed: ``self.query_norm(query)`` when the caller already has it (InteractionBlock shares
+        the statistics of c between the injector's feat_norm and this query_norm)."""
+        def body(query, feat, qn=None):
+            if qn is None:
+                query, qn = fused.layer_norm_keep(self.query_norm, query)
             feat, fn = fused.layer_norm_keep(self.feat_norm, feat, fan_out=True)
             attn = self.attn(qn, reference_points, fn, spatial_shapes, level_start_index, None)
             if self.with_cffn:
@@ -137,9 +141,9 @@ class Extractor(nn.Module):
             return out, feat
 
         if self.with_cp and query.requires_grad:
-            out, feat = cp.checkpoint(body, query, feat, use_reentrant=False)
+            out, feat = cp.checkpoint(body, query, feat, query_normed, use_reentrant=False)
         else:
-            out, feat = body(query, feat)
+            out, feat = body(query, feat, query_normed)
         return (out, feat) if keep_feat else out
 
 
@@ -156,18 +160,21 @@ class Injector(nn.Module):
                                  n_points=n_points, ratio=deform_ratio)
         self.gamma = nn.Parameter(init_values * torch.ones(dim), requires_grad=True)
 
-    def forward(self, query, reference_points, feat, spatial_shapes, level_start_index, keep_feat=False):
-        """keep_feat: see Extractor.forward (here ``feat`` is c, which the extractor consumes next)."""
-        def body(query, feat):
+    def forward(self, query, reference_points, feat, spatial_shapes, level_start_index, keep_feat=False,
+                feat_normed=None):
+        """keep_feat: see Extractor.forward (here ``feat`` is c, which the extractor consumes next).
+        feat_normed: ``self.feat_norm(feat)`` when the caller already has it."""
+        def body(query, feat, fn=None):
             query, qn = fused.layer_norm_keep(self.query_norm, query)
-            feat, fn = fused.layer_norm_keep(self.feat_norm, feat, fan_out=True)
+            if fn is None:
+                feat, fn = fused.layer_norm_keep(self.feat_norm, feat, fan_out=True)
             attn = self.attn(qn, reference_points, fn, spatial_shapes, level_start_index, None)
             return fused.residual(query, attn, self.gamma), feat
 
         if self.with_cp and query.requires_grad:
-            out, feat = cp.checkpoint(body, query, feat, use_reentrant=False)
+            out, feat = cp.checkpoint(body, query, feat, feat_normed, use_reentrant=False)
         else:
-            out, feat = body(query, feat)
+            out, feat = body(query, feat, feat_normed)
         return (out, feat) if keep_feat else out
 
 
@@ -192,20 +199,28 @@ class InteractionBlock(nn.Module):
         else:
             self.extra_extractors = None
 
-    def _extract(self, x, c, deform_inputs2, H, W):
+    def _extract(self, x, c, deform_inputs2, H, W, c_normed=None):
         stages = [self.extractor] + (list(self.extra_extractors) if self.extra_extractors is not None else [])
-        for stage in stages:
+        for k, stage in enumerate(stages):
             c, x = stage(query=c, reference_points=deform_inputs2[0], feat=x,
                          spatial_shapes=deform_inputs2[1], level_start_index=deform_inputs2[2],
-                         H=H, W=W, keep_feat=True)
+                         H=H, W=W, keep_feat=True, query_normed=c_normed if k == 0 else None)
         return x, c
 
+    def _inject(self, x, c, deform_inputs1):
+        """x <- injector(x, c).  c is normalised here for BOTH its consumers - the injector's feat_norm
+        and, since the injector leaves c unchanged, the first extractor's query_norm - with shared
+        statistics (one read of the 132 MB c stream, one backward pass).  Returns (x, c, query_norm(c))."""
+        c, cn_inj, cn_ext = fused.layer_norm_dual_keep(self.injector.feat_norm, self.extractor.query_norm, c)
+        x = self.injector(query=x, reference_points=deform_inputs1[0], feat=c,
+                          spatial_shapes=deform_inputs1[1], level_start_index=deform_inputs1[2],
+                          feat_normed=cn_inj)
+        return x, c, cn_ext
+
     def forward(self, x, c, blocks, deform_inputs1, deform_inputs2, H, W):
-        x, c = self.injector(query=x, reference_points=deform_inputs1[0], feat=c,
-                             spatial_shapes=deform_inputs1[1], level_start_index=deform_inputs1[2],
-                             keep_feat=True)
+        x, c, cn = self._inject(x, c, deform_inputs1)
         x = run_blocks(blocks, x, H, W)
-        return self._extract(x, c, deform_inputs2, H, W)
+        return self._extract(x, c, deform_inputs2, H, W, cn)
 
 
 class InteractionBlockWithCls(InteractionBlock):
@@ -213,13 +228,11 @@ class InteractionBlockWithCls(InteractionBlock):
     with_cls = True
 
     def forward(self, x, c, cls, blocks, deform_inputs1, deform_inputs2, H, W):
-        x, c = self.injector(query=x, reference_points=deform_inputs1[0], feat=c,
-                             spatial_shapes=deform_inputs1[1], level_start_index=deform_inputs1[2],
-                             keep_feat=True)
+        x, c, cn = self._inject(x, c, deform_inputs1)
         x = torch.cat((cls, x), dim=1)
         x = run_blocks(blocks, x, H, W)
         cls, x = x[:, :1], x[:, 1:]
-        x, c = self._extract(x, c, deform_inputs2, H, W)
+        x, c = self._extract(x, c, deform_inputs2, H, W, cn)
         return x, c, cls
 
 

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 import _vah
 
 ENABLED = {'layer_norm': True, 'residual': True, 'residual_ln': True, 'dwconv': True, 'linear': True, 'bn_tail': True,
-           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True, 'maps_in': True, 'linear_pair': True, 'maxpool': True, 'conv1x1': True}
+           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True, 'maps_in': True, 'linear_pair': True, 'maxpool': True, 'conv1x1': True, 'ln_dual': True}
 for _k in os.environ.get('VAH_FUSED_DISABLE', '').split(','):      # e.g. VAH_FUSED_DISABLE=residual_ln,bn_tail (A/B runs)
     if _k:
         ENABLED[_k.strip()] = False
@@ -86,6 +86,67 @@ def _ln_fusable(norm, x):
     return (ENABLED['layer_norm'] and x.is_cuda and x.dtype == torch.float32 and _bf16_autocast()
             and isinstance(norm, torch.nn.LayerNorm) and norm.elementwise_affine
             and x.shape[-1] % 4 == 0 and x.shape[-1] <= 2048 and x.numel() > 0)
+
+
+class _LayerNormDualBF16(torch.autograd.Function):
+    """(x, norm_a(x), norm_b(x)) for two LayerNorms of the same fp32 tensor (equal eps): statistics
+    shared, x read once; the backward sums the residual-branch gradient and both LayerNorm gradients in
+    one pass."""
+
+    @staticmethod
+    def forward(ctx, x, wa, ba, wb, bb, eps):
+        C = x.shape[-1]
+        xc = x.contiguous()
+        x2 = xc.view(-1, C)
+        rows = x2.shape[0]
+        ya = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        yb = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        wa, ba, wb, bb = (t.contiguous() for t in (wa, ba, wb, bb))
+        with torch.cuda.device(x.device):
+            _vah.check(_vah.lib.vah_layernorm_dual_fwd(
+                x2.data_ptr(), wa.data_ptr(), ba.data_ptr(), wb.data_ptr(), bb.data_ptr(), rows, C, float(eps),
+                ya.data_ptr(), yb.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream(x)), 'layernorm_dual_fwd')
+        ctx.save_for_backward(x2, wa, wb, mean, rstd)
+        ctx.shape = x.shape
+        ctx.set_materialize_grads(False)
+        return xc, ya, yb
+
+    @staticmethod
+    def backward(ctx, gres, ga, gb):
+        x2, wa, wb, mean, rstd = ctx.saved_tensors
+        rows, C = x2.shape
+        if ga is None and gb is None:
+            return (gres, None, None, None, None, None)
+        ga = ga.contiguous().to(torch.bfloat16) if ga is not None else None
+        gb = gb.contiguous().to(torch.bfloat16) if gb is not None else None
+        if gres is not None:
+            gres = gres.contiguous().float()
+        dx = torch.empty_like(x2)
+        dp = torch.empty(4, C, dtype=torch.float32, device=x2.device)
+        ws = _scratch(2 * C, x2.device)
+        with torch.cuda.device(x2.device):
+            _vah.check(_vah.lib.vah_layernorm_dual_bwd(
+                x2.data_ptr(), ga.data_ptr() if ga is not None else None, gb.data_ptr() if gb is not None else None,
+                wa.data_ptr(), wb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                gres.data_ptr() if gres is not None else None, rows, C, dx.data_ptr(), dp.data_ptr(), ws.data_ptr(),
+                _stream(x2)), 'layernorm_dual_bwd')
+        return dx.view(ctx.shape), dp[0], dp[1], dp[2], dp[3], None
+
+
+def layer_norm_dual_ok(norm_a, norm_b, x):
+    return (ENABLED['ln_dual'] and _ln_fusable(norm_a, x) and _ln_fusable(norm_b, x) and norm_a.eps == norm_b.eps
+            and x.shape[-1] <= 1024)
+
+
+def layer_norm_dual_keep(norm_a, norm_b, x):
+    """``(x, norm_a(x), norm_b(x))``; use the returned x downstream (see layer_norm_keep)."""
+    if layer_norm_dual_ok(norm_a, norm_b, x):
+        return _LayerNormDualBF16.apply(x, norm_a.weight, norm_a.bias, norm_b.weight, norm_b.bias, norm_a.eps)
+    x, ya = layer_norm_keep(norm_a, x, fan_out=True)
+    x, yb = layer_norm_keep(norm_b, x)
+    return x, ya, yb
 
 
 def layer_norm(norm, x):
