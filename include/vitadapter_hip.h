@@ -267,6 +267,9 @@ int vah_layernorm_dual_bwd(const float *x, const void *ga_bf16, const void *gb_b
 /* out[c] = sum_r g[r][c] of a bf16 (rows, C) matrix, C % 8 == 0: the bias gradient of nn.Linear
  * (what autograd computes as grad_output.sum(0)); ws K = C. */
 int vah_colsum_bf16(const void *g_bf16, int64_t rows, int64_t C, float *out, float *ws, void *stream);
+/* Only the partial rows (ws: vah_reduce_ws_floats(C), *nparts rows of C floats), for a consumer that sums them
+ * itself: vah_gemm_bf16_fin does it on its last launch. */
+int vah_colsum_bf16_partials(const void *g_bf16, int64_t rows, int64_t C, float *ws, int64_t *nparts, void *stream);
 /* fp32, over `batch` row blocks of a strided tensor: out[c] = sum_{b, r < rows} g[b * batch_stride + r * C + c]
  * (the gradient of a per-channel vector added to a token range of a (B, T, C) tensor); C % 4 == 0. */
 int vah_colsum_f32(const float *g, int64_t batch, int64_t batch_stride, int64_t rows, int64_t C, float *out,
@@ -351,6 +354,10 @@ int vah_gemm_set_tuning(int mode, int candidates);
 int vah_gemm_bf16(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
                   const void *B, int64_t ldb, void *D, int64_t ldd, int d_is_f32, int epilogue,
                   const void *bias, int bias_is_f32, void *workspace, int64_t workspace_bytes, void *stream);
+int vah_gemm_bf16_fin(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
+                      const void *B, int64_t ldb, void *D, int64_t ldd, int d_is_f32, void *workspace,
+                      int64_t workspace_bytes, const float *fin_part, int64_t fin_nparts, int64_t fin_C,
+                      float *fin_out, void *stream);   /* + fin_out[c] = sum_p fin_part[p * fin_C + c] */
 int64_t vah_gemm_library_version(void);                /* hipBLASLt build the algorithm indices belong to */
 int64_t vah_gemm_table_dump(char *buf, int64_t cap);   /* returns the size needed (incl. NUL) */
 int vah_gemm_table_load(const char *text);             /* returns the number of entries, < 0 on error */

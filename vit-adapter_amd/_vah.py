@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
-ABI_VERSION = 23
+ABI_VERSION = 24
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -84,6 +84,9 @@ _int = ctypes.c_int
 lib.vah_gemm_set_tuning.argtypes = [_int, _int]
 lib.vah_gemm_bf16.argtypes = [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _int, _int, _p, _int,
                               _p, _i64, _p]
+lib.vah_gemm_bf16_fin.argtypes = [_int, _int, _i64, _i64, _i64, _p, _i64, _p, _i64, _p, _i64, _int, _p, _i64, _p, _i64, _i64,
+                                  _p, _p]
+lib.vah_colsum_bf16_partials.argtypes = [_p, _i64, _i64, _p, ctypes.POINTER(_i64), _p]
 lib.vah_gemm_table_dump.argtypes = [ctypes.c_char_p, _i64]
 lib.vah_gemm_table_dump.restype = _i64
 lib.vah_gemm_table_load.argtypes = [ctypes.c_char_p]
@@ -108,7 +111,7 @@ lib.vah_dwconv3x3_tokens_bf16.argtypes = [_p, _p, _p, _i64, _i64, _i64, _i64, ct
 lib.vah_dwconv3x3_tokens_wgrad_bf16.argtypes = [_p, _p, _i64, _i64, _i64, _i64, _p, _p, _p, _p]
 for _n in ('vah_layernorm_fwd_f32_bf16', 'vah_layernorm_bwd_f32_bf16', 'vah_scale_residual_fwd',
            'vah_scale_residual_bwd', 'vah_dwconv3x3_tokens_bf16', 'vah_dwconv3x3_tokens_wgrad_bf16',
-           'vah_colsum_bf16', 'vah_colsum_f32', 'vah_layernorm_dual_fwd', 'vah_layernorm_dual_bwd', 'vah_residual_layernorm_fwd', 'vah_residual_layernorm_bwd', 'vah_gemm_set_tuning', 'vah_gemm_bf16', 'vah_gemm_table_load',
+           'vah_colsum_bf16', 'vah_colsum_f32', 'vah_layernorm_dual_fwd', 'vah_layernorm_dual_bwd', 'vah_residual_layernorm_fwd', 'vah_residual_layernorm_bwd', 'vah_gemm_set_tuning', 'vah_gemm_bf16', 'vah_gemm_bf16_fin', 'vah_colsum_bf16_partials', 'vah_gemm_table_load',
            'vah_bn_tail_stats', 'vah_bn_tail_apply', 'vah_bn_tail_bwd_stats', 'vah_bn_tail_bwd_apply',
            'vah_bn_finalize_stats', 'vah_transpose_tokens', 'vah_maxpool3s2_fwd_bf16', 'vah_maxpool3s2_bwd_bf16'):
     getattr(lib, _n).restype = ctypes.c_int
@@ -130,7 +133,7 @@ EXPORTS = (
     'vah_scale_residual_bwd', 'vah_dwconv3x3_tokens_bf16', 'vah_dwconv3x3_tokens_wgrad_bf16', 'vah_colsum_bf16', 'vah_colsum_f32',
     'vah_layernorm_dual_fwd', 'vah_layernorm_dual_bwd',
     'vah_residual_layernorm_fwd', 'vah_residual_layernorm_bwd',
-    'vah_gemm_set_tuning', 'vah_gemm_bf16', 'vah_gemm_table_dump', 'vah_gemm_table_load', 'vah_gemm_library_version',
+    'vah_gemm_set_tuning', 'vah_gemm_bf16', 'vah_gemm_bf16_fin', 'vah_colsum_bf16_partials', 'vah_gemm_table_dump', 'vah_gemm_table_load', 'vah_gemm_library_version',
     'vah_bn_tail_ws_floats', 'vah_bn_tail_stats', 'vah_bn_tail_apply', 'vah_bn_tail_bwd_stats', 'vah_bn_tail_bwd_apply',
     'vah_bn_finalize_stats', 'vah_transpose_tokens', 'vah_maxpool3s2_fwd_bf16', 'vah_maxpool3s2_bwd_bf16',
 )

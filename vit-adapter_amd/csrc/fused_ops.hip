@@ -924,6 +924,29 @@ int vah_layernorm_dual_bwd(const float *x, const void *ga, const void *gb, const
     return check_launch(fn);
 }
 
+// Partial rows of the column sums of a bf16 [rows, C] matrix, C % 8 == 0: ws (vah_reduce_ws_floats(C)) gets
+// *nparts rows of C floats; whoever sums them (vah_colsum_bf16 below, or the finalize job of
+// vah_gemm_bf16_fin) has the column sums.  rows >= 1.
+int vah_colsum_bf16_partials(const void *g, int64_t rows, int64_t C, float *ws, int64_t *nparts, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_colsum_bf16_partials";
+    if (rows < 1 || C < 8 || C % 8 || C > (1 << 20)) return fail(VAH_E_SHAPE, "%s: bad dims", fn);
+    if (!g || !ws || !nparts) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if ((uintptr_t)g % 16) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
+    const int ctiles = (int)((C + 255) / 256);
+    // enough strips to fill the chip, at least 32 rows each, at most kMaxParts partial rows
+    int64_t parts = std::min<int64_t>(kMaxParts, std::max<int64_t>(1, 2048 / ctiles));
+    int64_t rpb = std::max<int64_t>(32, (rows + parts - 1) / parts);
+    parts = (rows + rpb - 1) / rpb;
+    hipStream_t st = (hipStream_t)stream;
+    LaunchScope scope("colsum_bf16", rows * C * 2, st);
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)ctiles, (unsigned)parts), dim3(256), 0, st,
+                       (const __bf16 *)g, rows, (int)C, (int)rpb, ws);
+    *nparts = parts;
+    return check_launch(fn);
+}
+
 // out[c] = sum_r g[r][c] for a bf16 [rows, C] matrix, C % 8 == 0; ws: vah_reduce_ws_floats(C).
 int vah_colsum_bf16(const void *g, int64_t rows, int64_t C, float *out, float *ws, void *stream) {
     using namespace vah;
@@ -936,16 +959,8 @@ int vah_colsum_bf16(const void *g, int64_t rows, int64_t C, float *out, float *w
         (void)hipMemsetAsync(out, 0, C * 4, st);
         return VAH_OK;
     }
-    if (!g) return fail(VAH_E_NULL, "%s: null pointer", fn);
-    if ((uintptr_t)g % 16) return fail(VAH_E_ALIGN, "%s: misaligned", fn);
-    const int ctiles = (int)((C + 255) / 256);
-    // enough strips to fill the chip, at least 32 rows each, at most kMaxParts partial rows
-    int64_t parts = std::min<int64_t>(kMaxParts, std::max<int64_t>(1, 2048 / ctiles));
-    int64_t rpb = std::max<int64_t>(32, (rows + parts - 1) / parts);
-    parts = (rows + rpb - 1) / rpb;
-    LaunchScope scope("colsum_bf16", rows * C * 2, st);
-    hipLaunchKernelGGL(colsum_bf16_kernel, dim3((unsigned)ctiles, (unsigned)parts), dim3(256), 0, st,
-                       (const __bf16 *)g, rows, (int)C, (int)rpb, ws);
+    int64_t parts = 0;
+    if (int rc = vah_colsum_bf16_partials(g, rows, C, ws, &parts, stream)) return rc;
     hipLaunchKernelGGL(finalize_partials, dim3((unsigned)((C + 31) / 32)), dim3(256), 0, st, ws, (int)parts,
                        (int)C, out, (int)C, (float *)nullptr, 1 << 30, (float *)nullptr);
     return check_launch(fn);

@@ -98,6 +98,11 @@ struct Call {
     void *ws;
     size_t ws_bytes;
     hipStream_t st;
+    // optional finalize job riding on the reduction launch: out[c] = sum_p part[p][c] (the column-sum
+    // partials of the bias gradient), so a Linear backward needs one small launch less
+    const float *fin_part = nullptr;
+    int fin_nparts = 0, fin_C = 0;
+    float *fin_out = nullptr;
 };
 
 // split > 1: a strided batch over `split` equal slices of the K rows; the fp32 partial products
@@ -156,8 +161,34 @@ size_t partial_bytes(const Key &k, int split) {
 
 template <typename OT>
 __global__ __launch_bounds__(256) void reduce_splits(const float *__restrict__ part, int split, int64_t MN, int N,
-                                                     int64_t ldd, OT *__restrict__ out) {
-    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < MN; i += (int64_t)gridDim.x * 1024) {
+                                                     int64_t ldd, OT *__restrict__ out, int reduce_blocks,
+                                                     const float *__restrict__ fin_part, int fin_nparts, int fin_C,
+                                                     float *__restrict__ fin_out) {
+    if ((int)blockIdx.x >= reduce_blocks) {
+        // finalize job: 32 columns x 8 partial-row lanes per workgroup
+        __shared__ float s_acc[8][32];
+        const int col = threadIdx.x & 31, pl = threadIdx.x >> 5;
+        const int k = ((int)blockIdx.x - reduce_blocks) * 32 + col;
+        float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};      // 8 independent loads in flight per thread
+        if (k < fin_C) {
+            int p = pl;
+            for (; p + 56 < fin_nparts; p += 64) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) a8[u] += fin_part[(int64_t)(p + 8 * u) * fin_C + k];
+            }
+            for (; p < fin_nparts; p += 8) a8[0] += fin_part[(int64_t)p * fin_C + k];
+        }
+        s_acc[pl][col] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+        __syncthreads();
+        if (pl == 0 && k < fin_C) {
+            float t = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t += s_acc[u][col];
+            fin_out[k] = t;
+        }
+        return;
+    }
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < MN; i += (int64_t)reduce_blocks * 1024) {
         float4 acc = *reinterpret_cast<const float4 *>(part + i);
         for (int s = 1; s < split; ++s) {
             const float4 v = *reinterpret_cast<const float4 *>(part + s * MN + i);
@@ -183,15 +214,18 @@ hipblasStatus_t run(State &S, const Call &c, Problem &p, const hipblasLtMatmulAl
     // operands swapped: see the header comment
     const hipblasStatus_t s = hipblasLtMatmul(S.handle, p.desc, &alpha, c.B, p.la, c.A, p.lb, &beta, d, p.ld, d, p.ld, &algo,
                                               (char *)c.ws + pb, c.ws_bytes - pb, c.st);
-    if (s != HIPBLAS_STATUS_SUCCESS || split == 1) return s;
+    if (s != HIPBLAS_STATUS_SUCCESS) return s;
+    const bool fin = c.fin_part != nullptr;
+    if (split == 1 && !fin) return s;
     const int64_t MN = c.k.M * c.k.N;
-    const unsigned blocks = (unsigned)std::min<int64_t>(2048, (MN / 4 + 255) / 256);
+    const unsigned rblocks = split > 1 ? (unsigned)std::min<int64_t>(2048, (MN / 4 + 255) / 256) : 0u;
+    const unsigned fblocks = fin ? (unsigned)((c.fin_C + 31) / 32) : 0u;
     if (c.k.d32)
-        hipLaunchKernelGGL(reduce_splits<float>, dim3(blocks), dim3(256), 0, c.st, (const float *)c.ws, split, MN, (int)c.k.N,
-                           c.k.ldd, (float *)c.D);
+        hipLaunchKernelGGL(reduce_splits<float>, dim3(rblocks + fblocks), dim3(256), 0, c.st, (const float *)c.ws, split, MN,
+                           (int)c.k.N, c.k.ldd, (float *)c.D, (int)rblocks, c.fin_part, c.fin_nparts, c.fin_C, c.fin_out);
     else
-        hipLaunchKernelGGL(reduce_splits<__bf16>, dim3(blocks), dim3(256), 0, c.st, (const float *)c.ws, split, MN,
-                           (int)c.k.N, c.k.ldd, (__bf16 *)c.D);
+        hipLaunchKernelGGL(reduce_splits<__bf16>, dim3(rblocks + fblocks), dim3(256), 0, c.st, (const float *)c.ws, split, MN,
+                           (int)c.k.N, c.k.ldd, (__bf16 *)c.D, (int)rblocks, c.fin_part, c.fin_nparts, c.fin_C, c.fin_out);
     return HIPBLAS_STATUS_SUCCESS;
 }
 
@@ -304,7 +338,9 @@ std::vector<int> split_candidates(const State &S, const Call &c) {
     return v;
 }
 
-hipblasStatus_t choose(State &S, const Call &c, Choice &out) {
+hipblasStatus_t choose(State &S, const Call &call, Choice &out) {
+    Call c = call;                       // candidates are timed without the piggy-backed finalize job
+    c.fin_part = nullptr;
     const std::vector<int> splits = split_candidates(S, c);
     hipblasStatus_t last = HIPBLAS_STATUS_NOT_SUPPORTED;
     bool have = false;
@@ -356,12 +392,40 @@ int vah_gemm_set_tuning(int mode, int candidates) {
     return VAH_OK;
 }
 
+static int gemm_impl(const char *fn, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
+                     const void *B, int64_t ldb, void *D, int64_t ldd, int d_is_f32, int epilogue, const void *bias,
+                     int bias_is_f32, void *workspace, int64_t workspace_bytes, void *stream, const float *fin_part,
+                     int64_t fin_nparts, int64_t fin_C, float *fin_out);
+
 int vah_gemm_bf16(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
                   const void *B, int64_t ldb, void *D, int64_t ldd, int d_is_f32, int epilogue, const void *bias,
                   int bias_is_f32, void *workspace, int64_t workspace_bytes, void *stream) {
+    return gemm_impl("vah_gemm_bf16", trans_a, trans_b, M, N, K, A, lda, B, ldb, D, ldd, d_is_f32, epilogue, bias, bias_is_f32,
+                     workspace, workspace_bytes, stream, nullptr, 0, 0, nullptr);
+}
+
+// vah_gemm_bf16 plus a finalize job on its last launch: fin_out[c] = sum_{p < fin_nparts} fin_part[p * fin_C + c]
+// (the partial rows vah_colsum_bf16_partials wrote).  One Linear backward = partials, GEMM, reduction +
+// finalize: a launch less than column sum and weight gradient on their own.
+int vah_gemm_bf16_fin(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
+                      const void *B, int64_t ldb, void *D, int64_t ldd, int d_is_f32, void *workspace,
+                      int64_t workspace_bytes, const float *fin_part, int64_t fin_nparts, int64_t fin_C, float *fin_out,
+                      void *stream) {
+    using namespace vah;
+    if (!fin_part || !fin_out || fin_nparts < 1 || fin_C < 1 || fin_nparts > (1 << 20) || fin_C > (1 << 24)) {
+        clear_error();
+        return fail(VAH_E_SHAPE, "vah_gemm_bf16_fin: bad finalize job");
+    }
+    return gemm_impl("vah_gemm_bf16_fin", trans_a, trans_b, M, N, K, A, lda, B, ldb, D, ldd, d_is_f32, VAH_GEMM_EPI_NONE, nullptr,
+                     0, workspace, workspace_bytes, stream, fin_part, fin_nparts, fin_C, fin_out);
+}
+
+static int gemm_impl(const char *fn, int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, const void *A, int64_t lda,
+                     const void *B, int64_t ldb, void *D, int64_t ldd, int d_is_f32, int epilogue, const void *bias,
+                     int bias_is_f32, void *workspace, int64_t workspace_bytes, void *stream, const float *fin_part,
+                     int64_t fin_nparts, int64_t fin_C, float *fin_out) {
     using namespace vah;
     clear_error();
-    const char *fn = "vah_gemm_bf16";
     if (M < 0 || N < 0 || K < 0) return fail(VAH_E_SHAPE, "%s: negative dimension", fn);
     if (M == 0 || N == 0) return VAH_OK;
     if (K == 0) return fail(VAH_E_SHAPE, "%s: K = 0 (zero-fill the output instead)", fn);
@@ -379,6 +443,10 @@ int vah_gemm_bf16(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K, con
     }
     Call c{{trans_a ? 1 : 0, trans_b ? 1 : 0, d_is_f32 ? 1 : 0, epilogue, bias_is_f32 ? 1 : 0, M, N, K, lda, ldb, ldd},
            A, B, bias, D, workspace, (size_t)workspace_bytes, (hipStream_t)stream};
+    c.fin_part = fin_part;
+    c.fin_nparts = (int)fin_nparts;
+    c.fin_C = (int)fin_C;
+    c.fin_out = fin_out;
     hipblasStatus_t s = HIPBLAS_STATUS_SUCCESS;
     LaunchScope scope("gemm_bf16", (M * K + K * N) * 2 + M * N * (d_is_f32 ? 4 : 2), c.st);
     auto it = S.table.find(c.k);

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 import _vah
 
 ENABLED = {'layer_norm': True, 'residual': True, 'residual_ln': True, 'dwconv': True, 'linear': True, 'bn_tail': True,
-           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True, 'maps_in': True, 'linear_pair': True, 'maxpool': True, 'conv1x1': True, 'ln_dual': True}
+           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True, 'maps_in': True, 'linear_pair': True, 'maxpool': True, 'conv1x1': True, 'ln_dual': True, 'wgrad_fin': True}
 for _k in os.environ.get('VAH_FUSED_DISABLE', '').split(','):      # e.g. VAH_FUSED_DISABLE=residual_ln,bn_tail (A/B runs)
     if _k:
         ENABLED[_k.strip()] = False
@@ -289,6 +289,31 @@ def gemm_bf16(a, b, trans_a=False, trans_b=False, out_dtype=torch.bfloat16, bias
     return d
 
 
+def _wgrad_bgrad(g2, x2):
+    """(dW, db) = (g2^T x2 in fp32, column sums of g2) of a Linear backward: column-sum partials, the
+    (split-K) GEMM and ONE launch that both reduces the GEMM's slices and sums the partials."""
+    import ctypes
+    R, N = g2.shape
+    K = x2.shape[1]
+    if not _GEMM_TABLE_LOADED:
+        _load_gemm_table()
+    dev = g2.device
+    gw = torch.empty((N, K), dtype=torch.float32, device=dev)
+    gb = torch.empty(N, dtype=torch.float32, device=dev)
+    cws = _scratch(N, dev)
+    ws_bytes = _GEMM_WS_BYTES + (min(64 * N * K * 4, 160 << 20) if R >= 4096 else 0)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    nparts = ctypes.c_int64(0)
+    with torch.cuda.device(dev):
+        st = _stream(g2)
+        _vah.check(_vah.lib.vah_colsum_bf16_partials(g2.data_ptr(), R, N, cws.data_ptr(), ctypes.byref(nparts), st),
+                   'colsum_partials')
+        _vah.check(_vah.lib.vah_gemm_bf16_fin(1, 0, N, K, R, g2.data_ptr(), N, x2.data_ptr(), K, gw.data_ptr(), K, 1,
+                                              ws.data_ptr(), ws_bytes, cws.data_ptr(), nparts.value, N, gb.data_ptr(), st),
+                   'gemm_bf16_fin')
+    return gw, gb
+
+
 class _LinearBF16(torch.autograd.Function):
     """y = x W^T + b with bf16 operands and fp32 accumulation (what autocast makes of F.linear).
     Backward: dX in bf16, dW straight into fp32 from the GEMM (no bf16 rounding, no cast kernel),
@@ -324,17 +349,21 @@ class _LinearBF16(torch.autograd.Function):
             gx = gemm_bf16(g2, wb).view(ctx.in_shape)
             if gx.dtype != ctx.in_dtype:
                 gx = gx.to(ctx.in_dtype)
-        if ctx.needs_input_grad[1]:
-            if WGRAD_F32:
-                gw = gemm_bf16(g2, x2, trans_a=True, out_dtype=torch.float32)
-            else:
-                gw = gemm_bf16(g2, x2, trans_a=True).float()
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = torch.empty(N, dtype=torch.float32, device=g2.device)
-            ws = _scratch(N, g2.device)
-            with torch.cuda.device(g2.device):
-                _vah.check(_vah.lib.vah_colsum_bf16(g2.data_ptr(), g2.shape[0], N, gb.data_ptr(),
-                                                    ws.data_ptr(), _stream(g2)), 'colsum')
+        want_b = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] and want_b and WGRAD_F32 and g2.shape[0] > 0 and ENABLED['wgrad_fin']:
+            gw, gb = _wgrad_bgrad(g2, x2)
+        else:
+            if ctx.needs_input_grad[1]:
+                if WGRAD_F32:
+                    gw = gemm_bf16(g2, x2, trans_a=True, out_dtype=torch.float32)
+                else:
+                    gw = gemm_bf16(g2, x2, trans_a=True).float()
+            if want_b:
+                gb = torch.empty(N, dtype=torch.float32, device=g2.device)
+                ws = _scratch(N, g2.device)
+                with torch.cuda.device(g2.device):
+                    _vah.check(_vah.lib.vah_colsum_bf16(g2.data_ptr(), g2.shape[0], N, gb.data_ptr(),
+                                                        ws.data_ptr(), _stream(g2)), 'colsum')
         return gx, gw, gb
 
 
@@ -400,14 +429,19 @@ class _LinearPairBF16(torch.autograd.Function):
             gx = gemm_bf16(g, w).view(ctx.in_shape)
             if gx.dtype != ctx.in_dtype:
                 gx = gx.to(ctx.in_dtype)
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[3]:
-            gw = gemm_bf16(g, x2, trans_a=True, out_dtype=torch.float32)
-        if ctx.needs_input_grad[2] or ctx.needs_input_grad[4]:
-            gbias = torch.empty(na + nb, dtype=torch.float32, device=g.device)
-            ws = _scratch(na + nb, g.device)
-            with torch.cuda.device(g.device):
-                _vah.check(_vah.lib.vah_colsum_bf16(g.data_ptr(), R, na + nb, gbias.data_ptr(), ws.data_ptr(),
-                                                    _stream(g)), 'colsum')
+        want_w = ctx.needs_input_grad[1] or ctx.needs_input_grad[3]
+        want_b = ctx.needs_input_grad[2] or ctx.needs_input_grad[4]
+        if want_w and want_b and R > 0 and ENABLED['wgrad_fin']:
+            gw, gbias = _wgrad_bgrad(g, x2)
+        else:
+            if want_w:
+                gw = gemm_bf16(g, x2, trans_a=True, out_dtype=torch.float32)
+            if want_b:
+                gbias = torch.empty(na + nb, dtype=torch.float32, device=g.device)
+                ws = _scratch(na + nb, g.device)
+                with torch.cuda.device(g.device):
+                    _vah.check(_vah.lib.vah_colsum_bf16(g.data_ptr(), R, na + nb, gbias.data_ptr(), ws.data_ptr(),
+                                                        _stream(g)), 'colsum')
         return (gx, gw[:na] if gw is not None else None, gbias[:na] if gbias is not None else None,
                 gw[na:] if gw is not None else None, gbias[na:] if gbias is not None else None, None)
 
