@@ -203,8 +203,9 @@ __global__ __launch_bounds__(kBlock) void msda_fused_bwd(
     for (int l = 0; l < L; ++l) {
         const Level lv = read_level(shapes, lsi, l, S);
         const float2 rp = *reinterpret_cast<const float2 *>(ref + (q * ref_levels + (ref_levels > 1 ? l : 0)) * 2);
-        const VT *vl = value + head_off + lv.start * stride;
-        float *gvl = grad_value + head_off + lv.start * stride;
+        const int64_t lstart = lv.valid ? lv.start : 0;      // the gathers below are unconditional: stay in bounds
+        const VT *vl = value + head_off + lstart * stride;
+        float *gvl = grad_value + head_off + lstart * stride;
         Tap<float> t[P];
         float v[P][4];
         bool scatter[P];
@@ -219,8 +220,11 @@ __global__ __launch_bounds__(kBlock) void msda_fused_bwd(
 #pragma unroll
         for (int u = 0; u < P; ++u)
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-                v[u][k] = (lv.valid && t[u].ok[k]) ? (float)vl[(int64_t)t[u].row[k] * stride] : 0.f;
+            for (int k = 0; k < 4; ++k) {      // clamped load + select (a load under a condition is waited on alone)
+                const bool ok = lv.valid && t[u].ok[k];
+                const float x = (float)vl[(int64_t)(ok ? t[u].row[k] : 0) * stride];
+                v[u][k] = ok ? x : 0.f;
+            }
 #pragma unroll
         for (int u = 0; u < P; ++u) {
             const int s = l * P + u;
@@ -320,36 +324,53 @@ __global__ __launch_bounds__(kBlock) void msda_fused_bwd_vec4(
     const int64_t stride = (int64_t)M * kD;
     const int64_t head_off = n * S * stride + m * kD + sub * 4;
 
-    float p[LP], ga[LP], gx[LP], gy[LP];
+    // Register diet (this kernel waits on gathers: time ~ 1 / loads in flight per SIMD, i.e. it is
+    // paid in occupancy): the reduced per-sample sums are needed by ONE lane of the row only, so each
+    // lane keeps just the samples it will store (s & 7 == sub) instead of all LP x 3 of them.
+    constexpr int NM = (LP + 7) / 8;
+    float p[LP], ga_m[NM], gx_m[NM], gy_m[NM], p_m[NM];
     row_softmax<PT, LP>(logit + row * LP, p);
+#pragma unroll
+    for (int i = 0; i < NM; ++i) ga_m[i] = gx_m[i] = gy_m[i] = p_m[i] = 0.f;
+    float dot = 0.f;
+    const uint32_t row_bytes = (uint32_t)(stride * sizeof(VT));
+    const uint32_t lane_off = (uint32_t)(head_off * sizeof(VT));
     const float4 g = load4(grad_out + row * kD + sub * 4);
 #pragma unroll
     for (int l = 0; l < L; ++l) {
         const Level lv = read_level(shapes, lsi, l, S);
-        const VT *vl = value + head_off + lv.start * stride;
-        float *gvl = grad_value + head_off + lv.start * stride;
-        TapL t[P];
+        // 32-bit byte offsets from the (uniform) tensor base: one address register per gather instead
+        // of two (the host routes value tensors of 4 GB and more to msda_fused_bwd)
+        const int64_t lstart = lv.valid ? lv.start : 0;      // invalid level: rows are -1 -> token 0, selected away
+        const uint32_t lvl_off = lane_off + (uint32_t)lstart * row_bytes;
+        float *gvl = grad_value + head_off + lstart * stride;
+        const TapL *tp = s_tap + rl * LP + l * P;
         float4 v[P][4];
 #pragma unroll
-        for (int u = 0; u < P; ++u) t[u] = s_tap[rl * LP + l * P + u];
-#pragma unroll
-        for (int u = 0; u < P; ++u)
+        for (int u = 0; u < P; ++u) {
+            const int4 rw = *reinterpret_cast<const int4 *>(tp[u].row);
+            const int r4[4] = {rw.x, rw.y, rw.z, rw.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                v[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (t[u].row[k] >= 0) v[u][k] = load4(vl + (int64_t)t[u].row[k] * stride);
+                // unconditional (clamped) load + select: a load under `if (valid)` gets its own
+                // s_waitcnt and the 16 gathers of a row run one after the other
+                const float4 x = load4(reinterpret_cast<const VT *>(
+                    reinterpret_cast<const char *>(value) + (lvl_off + (uint32_t)max(r4[k], 0) * row_bytes)));
+                const bool ok = r4[k] >= 0;
+                v[u][k] = make_float4(ok ? x.x : 0.f, ok ? x.y : 0.f, ok ? x.z : 0.f, ok ? x.w : 0.f);
             }
+        }
 #pragma unroll
         for (int u = 0; u < P; ++u) {
             const int s = l * P + u;
             const float a = p[s];
-            const float lh = t[u].lh, lw = t[u].lw, hh = 1.f - lh, hw = 1.f - lw;
+            const float lh = tp[u].lh, lw = tp[u].lw, hh = 1.f - lh, hw = 1.f - lw;
             const float cw[4] = {hh * hw, hh * lw, lh * hw, lh * lw};
-            if (t[u].far) {
+            if (tp[u].far) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
-                    if (t[u].row[k] >= 0) {
-                        float *d = gvl + (int64_t)t[u].row[k] * stride;
+                    if (tp[u].row[k] >= 0) {
+                        float *d = gvl + (int64_t)tp[u].row[k] * stride;
                         const float w = cw[k] * a;
                         atomicAdd(d + 0, w * g.x);
                         atomicAdd(d + 1, w * g.y);
@@ -363,21 +384,24 @@ __global__ __launch_bounds__(kBlock) void msda_fused_bwd_vec4(
             const float val = cw[0] * d0 + cw[1] * d1 + cw[2] * d2 + cw[3] * d3;
             const float gh = hw * (d2 - d0) + lw * (d3 - d1);
             const float gw = hh * (d1 - d0) + lh * (d3 - d2);
-            ga[s] = sum8(val);
-            gx[s] = sum8(gw * a);
-            gy[s] = sum8(gh * a);
+            const float gas = sum8(val), gxs = sum8(gw * a), gys = sum8(gh * a);
+            dot += a * gas;
+            const bool mine = (s & 7) == sub;
+            ga_m[s >> 3] = mine ? gas : ga_m[s >> 3];
+            gx_m[s >> 3] = mine ? gxs : gx_m[s >> 3];
+            gy_m[s >> 3] = mine ? gys : gy_m[s >> 3];
+            p_m[s >> 3] = mine ? a : p_m[s >> 3];
         }
     }
-    float dot = 0.f;
-#pragma unroll
-    for (int s = 0; s < LP; ++s) dot += p[s] * ga[s];
     // LP <= 16 samples, 8 lanes: lane `sub` stores samples sub and sub + 8
 #pragma unroll
-    for (int s = 0; s < LP; ++s)
-        if ((s & 7) == sub) {
-            d_logit[row * LP + s] = (PT)(p[s] * (ga[s] - dot));
-            store2(d_off + (row * LP + s) * 2, gx[s], gy[s]);
+    for (int i = 0; i < NM; ++i) {
+        const int s = i * 8 + sub;
+        if (s < LP) {
+            d_logit[row * LP + s] = (PT)(p_m[i] * (ga_m[i] - dot));
+            store2(d_off + (row * LP + s) * 2, gx_m[i], gy_m[i]);
         }
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -753,7 +777,8 @@ int launch_bwd(const FusedArgs &a) {
     const int64_t nblocks = (rows + (kBlock / kD) - 1) / (kBlock / kD);
     const int64_t grid = (nblocks + 7) / 8 * 8;
     if (grid >= ((int64_t)1 << 31)) return fail(VAH_E_SHAPE, "msda fused backward: grid too large");
-    if (!a.tile_meta) {
+    const bool wide = a.N * a.S * a.M * kD * (int64_t)sizeof(VT) >= ((int64_t)1 << 32);   // vec4 kernel: 32-bit offsets
+    if (!a.tile_meta || wide) {
         hipLaunchKernelGGL((msda_fused_bwd<VT, PT, L, P>), dim3((unsigned)grid), dim3(kBlock), 0, a.st,
                            (const VT *)a.value, a.shapes, a.lsi, (const PT *)a.off, (const PT *)a.logit, a.ref,
                            a.ref_levels, (const VT *)a.grad_out, a.S, (int)a.M, a.Lq, rows, nblocks, -1.f,
