@@ -245,7 +245,7 @@ int vah_layernorm_bwd_f32_bf16(const float *x, const void *g_bf16, const float *
  *   fwd:  t = x + sc[b] * gamma * z (fp32, written),  h = LayerNorm(t) (bf16)
  *   bwd:  dt = gt + LayerNorm'(gh)  (= dx),  dz = sc * gamma * dt (bf16),  dgamma = sum sc * dt * z, dw, db
  * x, t (batch, rows_per_batch, C) fp32; z bf16; gamma (C), sc (batch), gt optional (NULL).
- * ws: vah_reduce_ws_floats(2 * C). */
+ * ws: vah_reduce_ws_floats(3 * C)  (partial rows [dw | db | dgamma]). */
 int vah_residual_layernorm_fwd(const float *x, const void *z_bf16, const float *gamma, const float *sc,
                                int64_t batch, int64_t rows_per_batch, int64_t C, const float *w, const float *b,
                                float eps, float *t, void *h_bf16, float *mean, float *rstd, void *stream);

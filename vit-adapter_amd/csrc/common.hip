@@ -83,7 +83,7 @@ LaunchScope::~LaunchScope() {
 
 extern "C" {
 
-int vah_abi_version(void) { return 24; }
+int vah_abi_version(void) { return 25; }
 
 const char *vah_last_error(void) { return vah::g_err; }
 

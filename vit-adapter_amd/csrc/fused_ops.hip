@@ -109,6 +109,9 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
 // an order of magnitude below the atomic rate (measured: the atomic version made the whole training
 // step 15 % slower).  Each workgroup writes one row of partials; finalize_partials sums the rows.
 constexpr int kMaxParts = 512;
+#ifndef VAH_LN_FLY
+#define VAH_LN_FLY 1           // rows in flight per wave in ln_bwd_kernel
+#endif
 
 // out[k] = sum_p part[p][k].  Workgroup = 32 columns x 8 partial-row lanes, 8 independent loads in
 // flight per thread (a one-thread-per-column loop over the rows is a 500-deep dependent-latency
@@ -142,9 +145,15 @@ __global__ __launch_bounds__(256) void finalize_partials(const float *__restrict
     }
 }
 
-// LayerNorm backward: a wave walks rows (grid stride), keeps per-column dw/db partials in
-// registers; the 4 waves of a workgroup are summed through LDS into one partial row [dw | db].
-template <int kMaxVec, int kWaves>
+// LayerNorm backward: a wave walks rows (grid stride); the waves of a workgroup are summed through
+// LDS into one partial row [dw | db] or, with a fused residual update in front, [dw | db | dgamma].
+//
+// Register budget decides this kernel: with the per-column accumulators and the affine weights in
+// registers it needed 256 VGPRs at C = 768 (2 waves per SIMD = ONE 8-wave workgroup per CU, so a
+// 512-workgroup grid ran as two back-to-back rounds, each a full load -> reduce -> store latency
+// chain).  The accumulators now live in the wave's own LDS row (plain read-add-write, no atomics:
+// nobody else touches it; ~100 LDS clocks per row) and the weights are read from LDS where used.
+template <int kMaxVec, int kWaves, bool kRes, int kFly>
 __global__ __launch_bounds__(64 * kWaves) void ln_bwd_kernel(const float *__restrict__ x,
                                                      const __bf16 *__restrict__ g,
                                                      const float *__restrict__ w,
@@ -153,39 +162,37 @@ __global__ __launch_bounds__(64 * kWaves) void ln_bwd_kernel(const float *__rest
                                                      const float *__restrict__ gres, int64_t rows, int C,
                                                      ResidualIn res, __bf16 *__restrict__ dz,
                                                      float *__restrict__ dx, float *__restrict__ part) {
-    // partial row: [dw | db] or, with a fused residual update in front, [dw | db | dgamma]
-    extern __shared__ __attribute__((aligned(16))) float s_red[];      // [kWaves][ncol * C]
+    constexpr int ncol = kRes ? 3 : 2;       // kRes: res.z != nullptr (compile time: its registers)
+    extern __shared__ __attribute__((aligned(16))) float s_red[];      // [kWaves][ncol * C] | w[C] | gamma[C]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nvec = C >> 2;
-    const int ncol = res.z ? 3 : 2;
-    float4 ww[kMaxVec], aw[kMaxVec], ab[kMaxVec], ag[kMaxVec], gm[kMaxVec];
-#pragma unroll
-    for (int j = 0; j < kMaxVec; ++j) {
-        const int i = lane + 64 * j;
-        ww[j] = aw[j] = ab[j] = ag[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        gm[j] = make_float4(1.f, 1.f, 1.f, 1.f);
-        if (i < nvec) {
-            ww[j] = *reinterpret_cast<const float4 *>(w + 4 * i);
-            if (res.z && res.gamma) gm[j] = *reinterpret_cast<const float4 *>(res.gamma + 4 * i);
-        }
+    float *acc = s_red + wv * ncol * C;                 // this wave's [dw | db | dgamma] sums
+    float *s_w = s_red + kWaves * ncol * C;
+    float *s_gm = s_w + C;
+    for (int k = lane; k < ncol * nvec; k += 64)
+        reinterpret_cast<float4 *>(acc)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = threadIdx.x; k < nvec; k += 64 * kWaves) {
+        reinterpret_cast<float4 *>(s_w)[k] = *reinterpret_cast<const float4 *>(w + 4 * k);
+        if constexpr (kRes)
+            reinterpret_cast<float4 *>(s_gm)[k] =
+                res.gamma ? *reinterpret_cast<const float4 *>(res.gamma + 4 * k) : make_float4(1.f, 1.f, 1.f, 1.f);
     }
+    __syncthreads();
     const float invC = 1.f / (float)C;
-    // Two rows per wave in flight: with <= 512 workgroups a wave walks only a few rows, and one row's
-    // loads -> two wave reductions -> stores is a serial chain (measured 45 us at 1.9 TB/s per call
-    // with one row in flight).
+    // kFly rows per wave in flight: one row's loads -> two wave reductions -> stores is a serial chain
     const int64_t stride = (int64_t)gridDim.x * kWaves;
-    for (int64_t row = (int64_t)blockIdx.x * kWaves + wv; row < rows; row += 2 * stride) {
-        int64_t rws[2] = {row, row + stride};
-        const int nrow = rws[1] < rows ? 2 : 1;
-        float4 xv[2][kMaxVec], rv[2][kMaxVec];
-        bf16x4 gv[2][kMaxVec], zv[2][kMaxVec];
-        float mu[2], rs[2], sb[2];
+    for (int64_t row = (int64_t)blockIdx.x * kWaves + wv; row < rows; row += kFly * stride) {
+        int64_t rws[kFly];
+        float4 xv[kFly][kMaxVec], rv[kFly][kMaxVec];
+        bf16x4 gv[kFly][kMaxVec], zv[kFly][kMaxVec];
+        float mu[kFly], rs[kFly], sb[kFly];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (u >= nrow) rws[u] = row;                 // harmless duplicate loads, results unused
+        for (int u = 0; u < kFly; ++u) {
+            rws[u] = row + u * stride;
+            if (rws[u] >= rows) rws[u] = row;            // harmless duplicate loads, results unused
             mu[u] = mean[rws[u]];
             rs[u] = rstd[rws[u]];
-            sb[u] = (res.z && res.sc) ? res.sc[rws[u] / res.rows_per_batch] : 1.f;
+            sb[u] = (kRes && res.sc) ? res.sc[rws[u] / res.rows_per_batch] : 1.f;
 #pragma unroll
             for (int j = 0; j < kMaxVec; ++j) {
                 const int i = lane + 64 * j;
@@ -194,13 +201,13 @@ __global__ __launch_bounds__(64 * kWaves) void ln_bwd_kernel(const float *__rest
                     gv[u][j] = *reinterpret_cast<const bf16x4 *>(g + rws[u] * C + 4 * i);
                     rv[u][j] = gres ? *reinterpret_cast<const float4 *>(gres + rws[u] * C + 4 * i)
                                     : make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (res.z) zv[u][j] = *reinterpret_cast<const bf16x4 *>(res.z + rws[u] * C + 4 * i);
+                    if constexpr (kRes) zv[u][j] = *reinterpret_cast<const bf16x4 *>(res.z + rws[u] * C + 4 * i);
                 }
             }
         }
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (u >= nrow) break;
+        for (int u = 0; u < kFly; ++u) {
+            if (row + u * stride >= rows) break;
             float4 xh[kMaxVec], gw[kMaxVec];
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -209,21 +216,26 @@ __global__ __launch_bounds__(64 * kWaves) void ln_bwd_kernel(const float *__rest
                 xh[j] = gw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (i < nvec) {
                     const float4 xr = xv[u][j];
+                    const float4 wj = *reinterpret_cast<const float4 *>(s_w + 4 * i);
                     const float g0 = (float)gv[u][j][0], g1 = (float)gv[u][j][1], g2 = (float)gv[u][j][2],
                                 g3 = (float)gv[u][j][3];
                     xh[j] = make_float4((xr.x - mu[u]) * rs[u], (xr.y - mu[u]) * rs[u], (xr.z - mu[u]) * rs[u],
                                         (xr.w - mu[u]) * rs[u]);
-                    gw[j] = make_float4(g0 * ww[j].x, g1 * ww[j].y, g2 * ww[j].z, g3 * ww[j].w);
+                    gw[j] = make_float4(g0 * wj.x, g1 * wj.y, g2 * wj.z, g3 * wj.w);
                     s1 += gw[j].x + gw[j].y + gw[j].z + gw[j].w;
                     s2 += gw[j].x * xh[j].x + gw[j].y * xh[j].y + gw[j].z * xh[j].z + gw[j].w * xh[j].w;
-                    aw[j].x += g0 * xh[j].x;
-                    aw[j].y += g1 * xh[j].y;
-                    aw[j].z += g2 * xh[j].z;
-                    aw[j].w += g3 * xh[j].w;
-                    ab[j].x += g0;
-                    ab[j].y += g1;
-                    ab[j].z += g2;
-                    ab[j].w += g3;
+                    float4 *pw = reinterpret_cast<float4 *>(acc + 4 * i), *pb = reinterpret_cast<float4 *>(acc + C + 4 * i);
+                    float4 aw = *pw, ab = *pb;
+                    aw.x += g0 * xh[j].x;
+                    aw.y += g1 * xh[j].y;
+                    aw.z += g2 * xh[j].z;
+                    aw.w += g3 * xh[j].w;
+                    ab.x += g0;
+                    ab.y += g1;
+                    ab.z += g2;
+                    ab.w += g3;
+                    *pw = aw;
+                    *pb = ab;
                 }
             }
             const float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
@@ -238,29 +250,24 @@ __global__ __launch_bounds__(64 * kWaves) void ln_bwd_kernel(const float *__rest
                         make_float4(r.x + k * (gw[j].x - m1 - xh[j].x * m2), r.y + k * (gw[j].y - m1 - xh[j].y * m2),
                                     r.z + k * (gw[j].z - m1 - xh[j].z * m2), r.w + k * (gw[j].w - m1 - xh[j].w * m2));
                     *reinterpret_cast<float4 *>(dr + 4 * i) = d;
-                    if (res.z) {                          // t = x + sc * gamma * z in front: dz, dgamma from dt = d
+                    if constexpr (kRes) {                 // t = x + sc * gamma * z in front: dz, dgamma from dt = d
+                        const float4 gm = *reinterpret_cast<const float4 *>(s_gm + 4 * i);
                         bf16x4 o;
-                        o[0] = (__bf16)(sb[u] * gm[j].x * d.x);
-                        o[1] = (__bf16)(sb[u] * gm[j].y * d.y);
-                        o[2] = (__bf16)(sb[u] * gm[j].z * d.z);
-                        o[3] = (__bf16)(sb[u] * gm[j].w * d.w);
+                        o[0] = (__bf16)(sb[u] * gm.x * d.x);
+                        o[1] = (__bf16)(sb[u] * gm.y * d.y);
+                        o[2] = (__bf16)(sb[u] * gm.z * d.z);
+                        o[3] = (__bf16)(sb[u] * gm.w * d.w);
                         *reinterpret_cast<bf16x4 *>(dz + rws[u] * C + 4 * i) = o;
-                        ag[j].x += sb[u] * d.x * (float)zv[u][j][0];
-                        ag[j].y += sb[u] * d.y * (float)zv[u][j][1];
-                        ag[j].z += sb[u] * d.z * (float)zv[u][j][2];
-                        ag[j].w += sb[u] * d.w * (float)zv[u][j][3];
+                        float4 *pg = reinterpret_cast<float4 *>(acc + 2 * C + 4 * i);
+                        float4 ag = *pg;
+                        ag.x += sb[u] * d.x * (float)zv[u][j][0];
+                        ag.y += sb[u] * d.y * (float)zv[u][j][1];
+                        ag.z += sb[u] * d.z * (float)zv[u][j][2];
+                        ag.w += sb[u] * d.w * (float)zv[u][j][3];
+                        *pg = ag;
                     }
                 }
             }
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < kMaxVec; ++j) {
-        const int i = lane + 64 * j;
-        if (i < nvec) {
-            *reinterpret_cast<float4 *>(s_red + wv * ncol * C + 4 * i) = aw[j];
-            *reinterpret_cast<float4 *>(s_red + wv * ncol * C + C + 4 * i) = ab[j];
-            if (res.z) *reinterpret_cast<float4 *>(s_red + wv * ncol * C + 2 * C + 4 * i) = ag[j];
         }
     }
     __syncthreads();
@@ -807,27 +814,32 @@ static int ln_bwd_launch(const char *fn, const float *x, const void *g, const fl
     // 8 waves per workgroup when their LDS reduction buffer leaves room for two workgroups per CU:
     // the partial-row cap bounds the grid at 512 workgroups, and with 4 waves each that is 2 waves per
     // SIMD - too few to cover the latency of this kernel's load -> reduce -> store chain
-    const int waves = (size_t)8 * ncol * C * sizeof(float) <= 76 * 1024 ? 8 : 4;
+    const size_t wbytes = (size_t)(res.z ? 2 : 1) * C * sizeof(float);      // affine weights kept in LDS
+    const int waves = (size_t)8 * ncol * C * sizeof(float) + wbytes <= 80 * 1024 ? 8 : 4;
     int64_t nblocks = (rows + waves - 1) / waves;
-    nblocks = std::min<int64_t>(nblocks, kMaxParts * 2 / ncol);          // the scratch holds kMaxParts * 2C floats
-    const size_t smem = (size_t)waves * ncol * C * sizeof(float);
+    nblocks = std::min<int64_t>(nblocks, kMaxParts);          // the scratch holds kMaxParts * ncol * C floats
+    const size_t smem = (size_t)waves * ncol * C * sizeof(float) + wbytes;
     LaunchScope scope(res.z ? "residual_layernorm_bwd" : "layernorm_bwd", rows * C * (res.z ? 18 : 10), st);
     if (smem > 150 * 1024) return fail(VAH_E_SHAPE, "%s: C too large for the fused form", fn);
-#define VAH_LN_BWD(NV, WV)                                                                       \
+constexpr int kLnFly = VAH_LN_FLY;
+#define VAH_LN_BWD(NV, WV, RS)                                                                     \
     do {                                                                                         \
         if (smem > 64 * 1024)                                                                    \
-            (void)hipFuncSetAttribute((const void *)ln_bwd_kernel<NV, WV>,                       \
+            (void)hipFuncSetAttribute((const void *)ln_bwd_kernel<NV, WV, RS, kLnFly>,                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);    \
-        hipLaunchKernelGGL((ln_bwd_kernel<NV, WV>), dim3((unsigned)nblocks), dim3(64 * WV), smem, st, x, \
+        hipLaunchKernelGGL((ln_bwd_kernel<NV, WV, RS, kLnFly>), dim3((unsigned)nblocks), dim3(64 * WV), smem, st, x, \
                            (const __bf16 *)g, w, mean, rstd, gres, rows, (int)C, res, (__bf16 *)dz, dx, ws); \
     } while (0)
 #define VAH_LN_BWD_W(NV)        \
     do {                        \
-        if (waves == 8) VAH_LN_BWD(NV, 8); \
-        else VAH_LN_BWD(NV, 4); \
+        if (waves == 8 && res.z) VAH_LN_BWD(NV, 8, true); \
+        else if (waves == 8) VAH_LN_BWD(NV, 8, false); \
+        else if (res.z) VAH_LN_BWD(NV, 4, true); \
+        else VAH_LN_BWD(NV, 4, false); \
     } while (0)
     if (C <= 256) VAH_LN_BWD_W(1);
     else if (C <= 512) VAH_LN_BWD_W(2);
+    else if (C <= 768) VAH_LN_BWD_W(3);
     else if (C <= 1024) VAH_LN_BWD_W(4);
     else VAH_LN_BWD_W(8);
 #undef VAH_LN_BWD_W
@@ -848,7 +860,7 @@ int vah_layernorm_bwd_f32_bf16(const float *x, const void *g, const float *w, co
 
 // Backward of vah_residual_layernorm_fwd: dt = gt + LayerNorm'(gh) (the gradient of x as well),
 // dz = sc * gamma * dt (bf16), dgamma = sum sc * dt * z, dw, db.  gt (gradient of t along the residual
-// stream) and gamma / sc / dgamma optional.  ws: vah_reduce_ws_floats(2*C).
+// stream) and gamma / sc / dgamma optional.  ws: vah_reduce_ws_floats(3*C).
 int vah_residual_layernorm_bwd(const float *t, const void *gh, const float *w, const float *mean, const float *rstd,
                                const float *gt, const void *z, const float *gamma, const float *sc, int64_t batch,
                                int64_t rows_per_batch, int64_t C, float *dt, void *dz, float *dgamma, float *dw,

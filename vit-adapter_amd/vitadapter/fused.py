@@ -620,7 +620,7 @@ class _ResidualLN(torch.autograd.Function):
         dt = torch.empty_like(t)
         dz = torch.empty_like(z)
         grads = torch.empty(3, C, dtype=torch.float32, device=dev)
-        ws = _scratch(2 * C, dev)
+        ws = _scratch(3 * C, dev)
         with torch.cuda.device(dev):
             _vah.check(_vah.lib.vah_residual_layernorm_bwd(
                 t.data_ptr(), gh.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
