@@ -651,20 +651,25 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const __bf16 *__restrict__ 
         const int H = mp.h[m], W = mp.w[m], t0 = mp.t[m];
         const int py = (tok - t0) / W, px = (tok - t0) - py * W;
         float4 acc = b4;
+        // all 9 neighbour rows are requested before the first is used (clamped coordinates, zero weight
+        // outside the map): loads under `if (inside)` each got their own s_waitcnt vmcnt(0)
+        bf16x4 v[9];
+        bool in[9];
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy)
+        for (int tap = 0; tap < 9; ++tap) {
+            const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+            in[tap] = yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+            v[tap] = *reinterpret_cast<const bf16x4 *>(x + ((b * N + t0 + (int64_t)yc * W + xc) * C + 4 * cv));
+        }
+        __builtin_amdgcn_sched_barrier(0);                  // keep the 9 loads above their uses (the scheduler sank them)
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int yy = py + dy, xx = px + dx;
-                if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-                const bf16x4 v = *reinterpret_cast<const bf16x4 *>(
-                    x + ((b * N + t0 + (int64_t)yy * W + xx) * C + 4 * cv));
-                const int tap = (dy + 1) * 3 + (dx + 1);     // flipped taps already folded into wt
-                acc.x += wt[0][tap] * (float)v[0];
-                acc.y += wt[1][tap] * (float)v[1];
-                acc.z += wt[2][tap] * (float)v[2];
-                acc.w += wt[3][tap] * (float)v[3];
-            }
+        for (int tap = 0; tap < 9; ++tap) {                 // flipped taps already folded into wt
+            acc.x += (in[tap] ? wt[0][tap] : 0.f) * (float)v[tap][0];
+            acc.y += (in[tap] ? wt[1][tap] : 0.f) * (float)v[tap][1];
+            acc.z += (in[tap] ? wt[2][tap] : 0.f) * (float)v[tap][2];
+            acc.w += (in[tap] ? wt[3][tap] : 0.f) * (float)v[tap][3];
+        }
         bf16x4 o;
         o[0] = (__bf16)acc.x;
         o[1] = (__bf16)acc.y;
@@ -702,18 +707,19 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const __bf16 *__restr
             const float gf[4] = {(float)gv[0], (float)gv[1], (float)gv[2], (float)gv[3]};
 #pragma unroll
             for (int c = 0; c < 4; ++c) ab[c] += gf[c];
+            bf16x4 v[9];                                        // all 9 neighbour rows in flight at once
+            bool in[9];
 #pragma unroll
-            for (int dy = -1; dy <= 1; ++dy)
+            for (int tap = 0; tap < 9; ++tap) {
+                const int yy = py + tap / 3 - 1, xx = px + tap % 3 - 1;
+                in[tap] = yy >= 0 && yy < H && xx >= 0 && xx < W;
+                const int yc = min(max(yy, 0), H - 1), xc = min(max(xx, 0), W - 1);
+                v[tap] = *reinterpret_cast<const bf16x4 *>(x + ((b * N + t0 + (int64_t)yc * W + xc) * C + 4 * cv));
+            }
 #pragma unroll
-                for (int dx = -1; dx <= 1; ++dx) {
-                    const int yy = py + dy, xx = px + dx;
-                    if (yy < 0 || yy >= H || xx < 0 || xx >= W) continue;
-                    const bf16x4 v = *reinterpret_cast<const bf16x4 *>(
-                        x + ((b * N + t0 + (int64_t)yy * W + xx) * C + 4 * cv));
-                    const int tap = (dy + 1) * 3 + (dx + 1);
+            for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) aw[c][tap] += gf[c] * (float)v[c];
-                }
+                for (int c = 0; c < 4; ++c) aw[c][tap] += (in[tap] ? gf[c] : 0.f) * (float)v[tap][c];
         }
     const int K = C * 10;
     if (live) {
