@@ -39,7 +39,7 @@ struct ResidualIn {
     float *sum;               // t out (forward) / unused (backward)
 };
 
-template <int kMaxVec>
+template <int kMaxVec, bool kRes>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x,
                                                      const float *__restrict__ w,
                                                      const float *__restrict__ b, int64_t rows, int C,
@@ -52,23 +52,36 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
     const float *xr = x + row * C;
     float4 v[kMaxVec];
     float s = 0.f;
-    const float sb = (res.z && res.sc) ? res.sc[row / res.rows_per_batch] : 1.f;
+    // every load of the row is requested before the first is used: with the residual operands read
+    // under `if (res.z)` inside the slot loop each slot waited for its own x / z / gamma round trip
+    bf16x4 zv[kMaxVec];
+    float4 gm[kMaxVec];
+    float sb = 1.f;
+    if constexpr (kRes) sb = res.sc ? res.sc[row / res.rows_per_batch] : 1.f;
+#pragma unroll
+    for (int j = 0; j < kMaxVec; ++j) {
+        const int i = min(lane + 64 * j, nvec - 1);          // clamped: dead slots re-read the last vector
+        v[j] = *reinterpret_cast<const float4 *>(xr + 4 * i);
+        if constexpr (kRes) {
+            zv[j] = *reinterpret_cast<const bf16x4 *>(res.z + row * C + 4 * i);
+            gm[j] = make_float4(1.f, 1.f, 1.f, 1.f);
+            if (res.gamma) gm[j] = *reinterpret_cast<const float4 *>(res.gamma + 4 * i);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int j = 0; j < kMaxVec; ++j) {
         const int i = lane + 64 * j;
-        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (i < nvec) {
-            v[j] = *reinterpret_cast<const float4 *>(xr + 4 * i);
-            if (res.z) {
-                const bf16x4 zv = *reinterpret_cast<const bf16x4 *>(res.z + row * C + 4 * i);
-                float4 gm = make_float4(1.f, 1.f, 1.f, 1.f);
-                if (res.gamma) gm = *reinterpret_cast<const float4 *>(res.gamma + 4 * i);
-                v[j].x += sb * gm.x * (float)zv[0];
-                v[j].y += sb * gm.y * (float)zv[1];
-                v[j].z += sb * gm.z * (float)zv[2];
-                v[j].w += sb * gm.w * (float)zv[3];
+            if constexpr (kRes) {
+                v[j].x += sb * gm[j].x * (float)zv[j][0];
+                v[j].y += sb * gm[j].y * (float)zv[j][1];
+                v[j].z += sb * gm[j].z * (float)zv[j][2];
+                v[j].w += sb * gm[j].w * (float)zv[j][3];
                 *reinterpret_cast<float4 *>(res.sum + row * C + 4 * i) = v[j];
             }
+        } else {
+            v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
         s += v[j].x + v[j].y + v[j].z + v[j].w;
     }
@@ -788,10 +801,17 @@ static int ln_fwd_launch(const char *fn, const float *x, const float *w, const f
     hipStream_t st = (hipStream_t)stream;
     LaunchScope scope(res.z ? "residual_layernorm_fwd" : "layernorm_fwd", rows * C * (res.z ? 12 : 6), st);
 #define VAH_LN_FWD(NV)                                                                          \
-    hipLaunchKernelGGL(ln_fwd_kernel<NV>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, w, b, \
-                       rows, (int)C, eps, res, (__bf16 *)y, mean, rstd)
+    do {                                                                                        \
+        if (res.z)                                                                              \
+            hipLaunchKernelGGL((ln_fwd_kernel<NV, true>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, w, b, \
+                               rows, (int)C, eps, res, (__bf16 *)y, mean, rstd);                \
+        else                                                                                    \
+            hipLaunchKernelGGL((ln_fwd_kernel<NV, false>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, w, b, \
+                               rows, (int)C, eps, res, (__bf16 *)y, mean, rstd);                \
+    } while (0)
     if (C <= 256) VAH_LN_FWD(1);
     else if (C <= 512) VAH_LN_FWD(2);
+    else if (C <= 768) VAH_LN_FWD(3);
     else if (C <= 1024) VAH_LN_FWD(4);
     else VAH_LN_FWD(8);
 #undef VAH_LN_FWD
