@@ -122,9 +122,6 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
 // an order of magnitude below the atomic rate (measured: the atomic version made the whole training
 // step 15 % slower).  Each workgroup writes one row of partials; finalize_partials sums the rows.
 constexpr int kMaxParts = 512;
-#ifndef VAH_LN_LDS_GAMMA
-#define VAH_LN_LDS_GAMMA 0     // 1: layer-scale gamma staged in LDS as well (3 KB more per workgroup)
-#endif
 #ifndef VAH_LN_FLY
 #define VAH_LN_FLY 1           // rows in flight per wave in ln_bwd_kernel
 #endif
@@ -169,9 +166,8 @@ __global__ __launch_bounds__(256) void finalize_partials(const float *__restrict
 // 512-workgroup grid ran as two back-to-back rounds, each a full load -> reduce -> store latency
 // chain).  The accumulators now live in the wave's own LDS row (plain read-add-write, no atomics:
 // nobody else touches it; ~100 LDS clocks per row) and the weights are read from LDS where used.
-constexpr bool kLdsGamma = VAH_LN_LDS_GAMMA;
 template <int kMaxVec, int kWaves, bool kRes, int kFly>
-__global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(kMaxVec <= 3 ? 4 : 1))) void ln_bwd_kernel(const float *__restrict__ x,
+__global__ __launch_bounds__(64 * kWaves) void ln_bwd_kernel(const float *__restrict__ x,
                                                      const __bf16 *__restrict__ g,
                                                      const float *__restrict__ w,
                                                      const float *__restrict__ mean,
@@ -190,7 +186,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(kMa
         reinterpret_cast<float4 *>(acc)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int k = threadIdx.x; k < nvec; k += 64 * kWaves) {
         reinterpret_cast<float4 *>(s_w)[k] = *reinterpret_cast<const float4 *>(w + 4 * k);
-        if constexpr (kRes && kLdsGamma)
+        if constexpr (kRes)
             reinterpret_cast<float4 *>(s_gm)[k] =
                 res.gamma ? *reinterpret_cast<const float4 *>(res.gamma + 4 * k) : make_float4(1.f, 1.f, 1.f, 1.f);
     }
@@ -255,15 +251,6 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(kMa
                     *pb = ab;
                 }
             }
-            // layer-scale gamma (3 KB, cache resident) is requested ahead of the two wave reductions so its
-            // latency hides behind them; unconditional load + select (a load under `if` is waited on alone)
-            float4 gmv[kMaxVec];
-            if constexpr (kRes && !kLdsGamma) {
-                const float *gp = res.gamma ? res.gamma : w;
-#pragma unroll
-                for (int j = 0; j < kMaxVec; ++j)
-                    gmv[j] = *reinterpret_cast<const float4 *>(gp + 4 * min(lane + 64 * j, nvec - 1));
-            }
             const float m1 = wave_sum(s1) * invC, m2 = wave_sum(s2) * invC;
             float *dr = dx + rws[u] * C;
 #pragma unroll
@@ -277,9 +264,7 @@ __global__ __launch_bounds__(64 * kWaves) __attribute__((amdgpu_waves_per_eu(kMa
                                     r.z + k * (gw[j].z - m1 - xh[j].z * m2), r.w + k * (gw[j].w - m1 - xh[j].w * m2));
                     *reinterpret_cast<float4 *>(dr + 4 * i) = d;
                     if constexpr (kRes) {                 // t = x + sc * gamma * z in front: dz, dgamma from dt = d
-                        float4 gm = make_float4(1.f, 1.f, 1.f, 1.f);
-                        if constexpr (kLdsGamma) gm = *reinterpret_cast<const float4 *>(s_gm + 4 * i);
-                        else if (res.gamma) gm = gmv[j];
+                        const float4 gm = *reinterpret_cast<const float4 *>(s_gm + 4 * i);
                         bf16x4 o;
                         o[0] = (__bf16)(sb[u] * gm.x * d.x);
                         o[1] = (__bf16)(sb[u] * gm.y * d.y);
@@ -855,7 +840,7 @@ static int ln_bwd_launch(const char *fn, const float *x, const void *g, const fl
     // 8 waves per workgroup when their LDS reduction buffer leaves room for two workgroups per CU:
     // the partial-row cap bounds the grid at 512 workgroups, and with 4 waves each that is 2 waves per
     // SIMD - too few to cover the latency of this kernel's load -> reduce -> store chain
-    const size_t wbytes = (size_t)((res.z && kLdsGamma) ? 2 : 1) * C * sizeof(float);      // affine weights kept in LDS
+    const size_t wbytes = (size_t)(res.z ? 2 : 1) * C * sizeof(float);      // affine weights kept in LDS
     const int waves = (size_t)8 * ncol * C * sizeof(float) + wbytes <= 80 * 1024 ? 8 : 4;
     int64_t nblocks = (rows + waves - 1) / waves;
     nblocks = std::min<int64_t>(nblocks, kMaxParts);          // the scratch holds kMaxParts * ncol * C floats
