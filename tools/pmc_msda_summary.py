@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""Summarise rocprofv3 --pmc passes of tools/prof_msda_single.py into profiles/r01_msda_pmc.json.
+
+Layout expected (one directory per pass, csv output):
+    <root>/<cfg>_n<noise>_<COUNTER>/**/*counter_collection.csv      COUNTER in FETCH_SIZE, WRITE_SIZE
+    python tools/pmc_msda_summary.py <root> <iters> > profiles/r01_msda_pmc.json
+Counter unit KiB.  hbm_bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (gfx950: FETCH_SIZE reports half of
+the bytes of wide coalesced reads, MI355X_MICROARCH.md "HBM"); per call = sum over the kernels of one
+forward (msda_fused_fwd) / backward (msda_fused_bwd_vec4 + msda_fused_bwd_gv_mfma) call.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def main():
+    root, iters = sys.argv[1], int(sys.argv[2])
+    acc = defaultdict(lambda: defaultdict(float))          # (cfg_noise, dir) -> counter -> KiB per call
+    for d in sorted(glob.glob(os.path.join(root, '*_*SIZE'))):
+        base = os.path.basename(d)
+        counter = 'FETCH_SIZE' if base.endswith('FETCH_SIZE') else 'WRITE_SIZE'
+        key = base[:-len(counter) - 1]
+        files = glob.glob(os.path.join(d, '**', '*counter_collection.csv'), recursive=True)
+        if not files:
+            continue
+        for r in csv.DictReader(open(files[0])):
+            if r['Counter_Name'] != counter:
+                continue
+            n = r['Kernel_Name']
+            if 'msda_fused_fwd' in n:
+                acc[(key, 'fwd')][counter] += float(r['Counter_Value']) / iters
+            elif 'msda_fused_bwd' in n:
+                acc[(key, 'bwd')][counter] += float(r['Counter_Value']) / iters
+    out = {'_note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace only) of '
+                    'tools/prof_msda_single.py <cfg> %d <noise> (fused MSDA core, bf16 IO), MI355X, kernels as committed at the '
+                    'end of round 1.  n0 = offsets of a freshly initialised model (what bench.py runs: no far samples), '
+                    'n1 = ring bias + N(0,1) px ("adapter" offsets: ~4 %% far samples, scattered with float atomics by '
+                    'msda_fused_bwd_vec4).  Counter unit KiB; per call = sum over the kernels of one forward / backward call. '
+                    'hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 correction of MI355X_MICROARCH.md).' % iters}
+    for (key, d), c in sorted(acc.items()):
+        f, w = c.get('FETCH_SIZE', 0.0), c.get('WRITE_SIZE', 0.0)
+        out['%s_%s' % (key, d)] = {'FETCH_SIZE_KiB': round(f, 1), 'WRITE_SIZE_KiB': round(w, 1),
+                                   'hbm_bytes_per_launch': int(2 * f * 1024 + w * 1024)}
+    # the keys bench.py reads: the bench-like (n0) numbers
+    for cfg in ('cfg3_inj', 'cfg3_ext'):
+        for d in ('fwd', 'bwd'):
+            k = '%s_n0_%s' % (cfg, d)
+            if k in out:
+                out['%s_%s' % (cfg, d)] = out[k]
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """A few launches of the fused MSDA core (forward + backward, bf16 IO as in bench.py) at a BASELINE
 call shape, for rocprofv3 --pmc runs (FETCH_SIZE / WRITE_SIZE per launch -> roofline.traffic).
-Usage: prof_msda_single.py cfg3_ext [iters]"""
+Usage: prof_msda_single.py cfg3_ext [iters] [offset noise in px: 1 = "adapter" offsets, 0 = the ring bias of a
+freshly initialised model, which is what bench.py runs]"""
 import os
 import sys
 
@@ -15,13 +16,14 @@ from ops.functions import MSDeformAttnFusedFunction  # noqa: E402
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else 'cfg3_ext'
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+noise = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 dt = torch.bfloat16
 N, M, D, P, Lq, shapes, qshapes = cases.bench_inputs(cfg)
 L, S = len(shapes), sum(h * w for h, w in shapes)
 g = torch.Generator(device='cuda').manual_seed(0)
 value = torch.randn(N, S, M, D, device='cuda', generator=g).to(dt).requires_grad_(True)
 off = (cases.ring_offsets(M, L, P).cuda()[None, None]
-       + torch.randn(N, Lq, M, L, P, 2, device='cuda', generator=g)).to(dt).requires_grad_(True)
+       + noise * torch.randn(N, Lq, M, L, P, 2, device='cuda', generator=g)).to(dt).requires_grad_(True)
 logit = torch.randn(N, Lq, M, L * P, device='cuda', generator=g).to(dt).requires_grad_(True)
 ref = cases.reference_grid(qshapes).cuda()
 hw = torch.as_tensor(shapes, dtype=torch.long, device='cuda')
