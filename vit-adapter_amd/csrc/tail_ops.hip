@@ -44,13 +44,15 @@ struct Tap {
     float w1;
 };
 
-__device__ __forceinline__ Tap tap_of(int d, int n_lo, float inv_scale) {
-    float src = ((float)d + 0.5f) * inv_scale - 0.5f;
-    src = src < 0.f ? 0.f : src;
+// scale = 2^k (host-checked): src = (2d + 1 - s) / 2s exactly, so floor and fraction are integer ops;
+// same values as the float form  src = (d + 0.5) / s - 0.5, clamped at 0  (both are exact in fp32).
+__device__ __forceinline__ Tap tap_of(int d, int n_lo, int s) {
+    const int sh1 = 32 - __builtin_clz((unsigned)s);            // log2(2s)
+    const int n = max(2 * d + 1 - s, 0);
     Tap t;
-    t.i0 = min((int)src, n_lo - 1);
+    t.i0 = min(n >> sh1, n_lo - 1);
     t.i1 = min(t.i0 + 1, n_lo - 1);
-    t.w1 = src - (float)t.i0;
+    t.w1 = (float)(n & (2 * s - 1)) * (0.5f / (float)s);
     return t;
 }
 
@@ -60,6 +62,38 @@ __device__ __forceinline__ float4 load4(const void *p, int64_t idx, int is_bf16)
         return make_float4((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
     }
     return *reinterpret_cast<const float4 *>(reinterpret_cast<const float *>(p) + idx);
+}
+
+// Raw 4-element load (4 fp32 or 4 bf16, dtype uniform) and its decode, kept apart so that a kernel can
+// request all of its operands before it touches the first: with the conversion next to the load (load4)
+// every operand sat in its own uniform branch with its own s_waitcnt vmcnt(0).
+struct Raw4 {
+    uint32_t w0, w1, w2, w3;
+};
+
+__device__ __forceinline__ Raw4 load_raw(const void *p, int64_t idx, int is_bf16) {
+    Raw4 r;
+    r.w0 = r.w1 = r.w2 = r.w3 = 0u;
+    if (is_bf16) {
+        const uint2 v = *reinterpret_cast<const uint2 *>(reinterpret_cast<const __bf16 *>(p) + idx);
+        r.w0 = v.x;
+        r.w1 = v.y;
+    } else {
+        const uint4 v = *reinterpret_cast<const uint4 *>(reinterpret_cast<const float *>(p) + idx);
+        r.w0 = v.x;
+        r.w1 = v.y;
+        r.w2 = v.z;
+        r.w3 = v.w;
+    }
+    return r;
+}
+
+__device__ __forceinline__ float4 decode(const Raw4 &r, int is_bf16) {
+    const float4 h = make_float4(__uint_as_float(r.w0 << 16), __uint_as_float(r.w0 & 0xffff0000u),
+                                 __uint_as_float(r.w1 << 16), __uint_as_float(r.w1 & 0xffff0000u));
+    const float4 f = make_float4(__uint_as_float(r.w0), __uint_as_float(r.w1), __uint_as_float(r.w2),
+                                 __uint_as_float(r.w3));
+    return is_bf16 ? h : f;
 }
 
 __device__ __forceinline__ void store4(void *p, int64_t idx, int is_bf16, float4 v) {
@@ -76,41 +110,72 @@ __device__ __forceinline__ void store4(void *p, int64_t idx, int is_bf16, float4
 }
 
 // t = a + b + up(x) for 4 consecutive pixels (row y, columns x4 .. x4 + 3) of plane `plane`.
-__device__ __forceinline__ float4 sum4(const Operands &o, int64_t plane, int y, int x4) {
+// Every load (a, b, the 8 low-res values, and the caller's dy when `dy` is given) is requested before the
+// first is decoded.
+__device__ __forceinline__ float4 sum4(const Operands &o, int64_t plane, int y, int x4, const void *dy = nullptr,
+                                       Raw4 *dy_raw = nullptr) {
     const int64_t idx = (plane * o.H + y) * o.W + x4;
-    float4 t = load4(o.a, idx, o.a_bf16);
-    if (o.shift) {
-        const float sft = o.shift[plane % o.C];
-        t.x += sft;
-        t.y += sft;
-        t.z += sft;
-        t.w += sft;
-    }
-    if (o.b) {
-        const float4 v = load4(o.b, idx, o.b_bf16);
-        t.x += v.x;
-        t.y += v.y;
-        t.z += v.z;
-        t.w += v.w;
-    }
+    const Raw4 ra = load_raw(o.a, idx, o.a_bf16);
+    Raw4 rb;
+    rb.w0 = rb.w1 = rb.w2 = rb.w3 = 0u;
+    if (o.b) rb = load_raw(o.b, idx, o.b_bf16);
+    if (dy) *dy_raw = load_raw(dy, idx, o.dy_bf16);
+    float sft = 0.f;
+    if (o.shift) sft = o.shift[plane % o.C];
+    float4 xs = make_float4(0.f, 0.f, 0.f, 0.f);          // scale 1: the low-res row itself
+    float c0[4] = {0.f, 0.f, 0.f, 0.f}, c1[4] = {0.f, 0.f, 0.f, 0.f};
+    Tap ty;
+    ty.i0 = ty.i1 = 0;
+    ty.w1 = 0.f;
+    int nx0 = 0, bcol = 0;
+    const int sc = o.scale, sh1 = 32 - __builtin_clz((unsigned)sc), mask = 2 * sc - 1;
     if (o.x) {
         const float *xp = o.x + plane * o.Hl * o.Wl;
-        if (o.scale == 1) {
-            const float4 v = *reinterpret_cast<const float4 *>(xp + (int64_t)y * o.Wl + x4);
-            t.x += v.x;
-            t.y += v.y;
-            t.z += v.z;
-            t.w += v.w;
+        if (sc == 1) {
+            xs = *reinterpret_cast<const float4 *>(xp + (int64_t)y * o.Wl + x4);
         } else {
-            const float inv = 1.f / (float)o.scale;
-            const Tap ty = tap_of(y, o.Hl, inv);
+            // 4 consecutive pixels starting at a multiple of 4 read at most 4 consecutive low-res columns
+            // (b .. b + 3, b = floor of the first pixel's source position): 8 loads instead of 16, the
+            // pixel's pair picked with selects.  Index clamping at the borders gives what the clamped
+            // source position gives: both taps on the same column, r + w * (r - r) = r.
+            ty = tap_of(y, o.Hl, sc);
             const float *r0 = xp + (int64_t)ty.i0 * o.Wl, *r1 = xp + (int64_t)ty.i1 * o.Wl;
+            nx0 = 2 * x4 + 1 - sc;
+            bcol = nx0 >> sh1;                               // arithmetic shift: floor, >= -1
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cj = min(max(bcol + j, 0), o.Wl - 1);
+                c0[j] = r0[cj];
+                c1[j] = r1[cj];
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);                       // loads above, arithmetic below
+    float4 t = decode(ra, o.a_bf16);
+    const float4 vb = decode(rb, o.b_bf16);
+    t.x += sft + vb.x;
+    t.y += sft + vb.y;
+    t.z += sft + vb.z;
+    t.w += sft + vb.w;
+    if (o.x) {
+        if (sc == 1) {
+            t.x += xs.x;
+            t.y += xs.y;
+            t.z += xs.z;
+            t.w += xs.w;
+        } else {
+            const float inv2s = 0.5f / (float)sc;
             float u[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const Tap tx = tap_of(x4 + k, o.Wl, inv);
-                const float top = r0[tx.i0] + tx.w1 * (r0[tx.i1] - r0[tx.i0]);
-                const float bot = r1[tx.i0] + tx.w1 * (r1[tx.i1] - r1[tx.i0]);
+                const int nk = nx0 + 2 * k, ik = (nk >> sh1) - bcol;      // 0, 1 or 2
+                const float w1 = (float)(nk & mask) * inv2s;
+                const float a0 = ik == 0 ? c0[0] : (ik == 1 ? c0[1] : c0[2]);
+                const float a1 = ik == 0 ? c0[1] : (ik == 1 ? c0[2] : c0[3]);
+                const float b0 = ik == 0 ? c1[0] : (ik == 1 ? c1[1] : c1[2]);
+                const float b1 = ik == 0 ? c1[1] : (ik == 1 ? c1[2] : c1[3]);
+                const float top = a0 + w1 * (a1 - a0);
+                const float bot = b0 + w1 * (b1 - b0);
                 u[k] = top + ty.w1 * (bot - top);
             }
             t.x += u[0];
@@ -179,9 +244,8 @@ __global__ __launch_bounds__(256) void tail_apply_kernel(Operands o, const float
 }
 
 // Gradient reaching the normalisation output: dy, masked by the fused ReLU (y recomputed, not stored).
-__device__ __forceinline__ float4 grad4(const Operands &o, const void *dy, int64_t idx, const float4 &t, float sc,
-                                        float sh) {
-    float4 g = load4(dy, idx, o.dy_bf16);
+__device__ __forceinline__ float4 grad4(const Operands &o, const Raw4 &dy_raw, const float4 &t, float sc, float sh) {
+    float4 g = decode(dy_raw, o.dy_bf16);
     if (o.relu) {
         g.x = t.x * sc + sh > 0.f ? g.x : 0.f;
         g.y = t.y * sc + sh > 0.f ? g.y : 0.f;
@@ -210,8 +274,9 @@ __global__ __launch_bounds__(256) void tail_bwd_stats_kernel(Operands o, const f
     float s1 = 0.f, s2 = 0.f;
     for (int i = threadIdx.x; i < (r1 - r0) * wv4; i += 256) {
         const int yy = r0 + i / wv4, x4 = (i % wv4) * 4;
-        const float4 t = sum4(o, plane, yy, x4);
-        const float4 g = grad4(o, dy, (plane * o.H + yy) * o.W + x4, t, sc, sh);
+        Raw4 rdy;
+        const float4 t = sum4(o, plane, yy, x4, dy, &rdy);
+        const float4 g = grad4(o, rdy, t, sc, sh);
         s1 += (g.x + g.y) + (g.z + g.w);
         s2 += (g.x * (t.x - mu) + g.y * (t.y - mu)) + (g.z * (t.z - mu) + g.w * (t.w - mu));
     }
@@ -250,8 +315,9 @@ __global__ __launch_bounds__(256) void tail_bwd_apply_kernel(Operands o, const f
     for (int i = threadIdx.x; i < rows * wv4; i += 256) {
         const int yy = r0 + i / wv4, x4 = (i % wv4) * 4;
         const int64_t idx = (plane * o.H + yy) * o.W + x4;
-        const float4 t = sum4(o, plane, yy, x4);
-        const float4 g = grad4(o, dy, idx, t, k, sh);
+        Raw4 rdy;
+        const float4 t = sum4(o, plane, yy, x4, dy, &rdy);
+        const float4 g = grad4(o, rdy, t, k, sh);
         const float4 d = make_float4(k * (g.x - m1 - (t.x - mu) * rs * m2), k * (g.y - m1 - (t.y - mu) * rs * m2),
                                      k * (g.z - m1 - (t.z - mu) * rs * m2), k * (g.w - m1 - (t.w - mu) * rs * m2));
         if (da) store4(da, idx, o.a_bf16, d);
@@ -263,7 +329,6 @@ __global__ __launch_bounds__(256) void tail_bwd_apply_kernel(Operands o, const f
     }
     if (!want_lo || o.scale == 1) return;
     __syncthreads();
-    const float inv = 1.f / (float)o.scale;
     const int s = o.scale;
     float *s_col = s_tile + rows * o.W;                                  // [rows][Wl]
     for (int i = threadIdx.x; i < rows * o.Wl; i += 256) {
@@ -272,21 +337,21 @@ __global__ __launch_bounds__(256) void tail_bwd_apply_kernel(Operands o, const f
         float acc = 0.f;
         const int xa = max(0, s * (j - 1)), xb = min(o.W - 1, s * (j + 2) - 1);
         for (int x = xa; x <= xb; ++x) {
-            const Tap t = tap_of(x, o.Wl, inv);
+            const Tap t = tap_of(x, o.Wl, s);
             const float w = (t.i0 == j ? 1.f - t.w1 : 0.f) + (t.i1 == j ? t.w1 : 0.f);
             acc += w * row[x];
         }
         s_col[i] = acc;
     }
     __syncthreads();
-    const int i_lo = tap_of(r0, o.Hl, inv).i0, i_hi = tap_of(r1 - 1, o.Hl, inv).i1;
+    const int i_lo = tap_of(r0, o.Hl, s).i0, i_hi = tap_of(r1 - 1, o.Hl, s).i1;
     float *out = dxlo + plane * o.Hl * o.Wl;
     for (int i = threadIdx.x; i < (i_hi - i_lo + 1) * o.Wl; i += 256) {
         const int li = i_lo + i / o.Wl, j = i % o.Wl;
         const int ya = max(r0, s * (li - 1)), yb = min(r1 - 1, s * (li + 2) - 1);
         float acc = 0.f;
         for (int y = ya; y <= yb; ++y) {
-            const Tap t = tap_of(y, o.Hl, inv);
+            const Tap t = tap_of(y, o.Hl, s);
             const float w = (t.i0 == li ? 1.f - t.w1 : 0.f) + (t.i1 == li ? t.w1 : 0.f);
             acc += w * s_col[(y - r0) * o.Wl + j];
         }
