@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void ln_dual_fwd_kernel(const float *__restric
 
 // partial row: [dwa | dba | dwb | dbb]
 template <int kMaxVec>
-__global__ __launch_bounds__(256) void ln_dual_bwd_kernel(const float *__restrict__ x, const __bf16 *__restrict__ ga,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(kMaxVec <= 3 ? 3 : 1))) void ln_dual_bwd_kernel(const float *__restrict__ x, const __bf16 *__restrict__ ga,
                                                           const __bf16 *__restrict__ gb, const float *__restrict__ wa,
                                                           const float *__restrict__ wb, const float *__restrict__ mean,
                                                           const float *__restrict__ rstd, const float *__restrict__ gres,
@@ -385,15 +385,35 @@ __global__ __launch_bounds__(256) void ln_dual_bwd_kernel(const float *__restric
         const float mu = mean[row], rs = rstd[row];
         float4 xh[kMaxVec], gw[kMaxVec], rv[kMaxVec];
         float s1 = 0.f, s2 = 0.f;
+        // every load of the row is requested before the first is used (optional operands: a valid
+        // stand-in address + select): with the loads under `ga ? .. : ..` inside the slot loop each vector
+        // slot paid its own memory round trip, three per row
+        float4 xl[kMaxVec];
+        bf16x4 g1l[kMaxVec], g2l[kMaxVec];
+        {
+            const __bf16 *gap = ga ? ga : reinterpret_cast<const __bf16 *>(x);
+            const __bf16 *gbp = gb ? gb : reinterpret_cast<const __bf16 *>(x);
+            const float *grp = gres ? gres : x;
+#pragma unroll
+            for (int j = 0; j < kMaxVec; ++j) {
+                const int i = min(lane + 64 * j, nvec - 1);
+                xl[j] = *reinterpret_cast<const float4 *>(x + row * C + 4 * i);
+                g1l[j] = *reinterpret_cast<const bf16x4 *>(gap + row * C + 4 * i);
+                g2l[j] = *reinterpret_cast<const bf16x4 *>(gbp + row * C + 4 * i);
+                rv[j] = *reinterpret_cast<const float4 *>(grp + row * C + 4 * i);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int j = 0; j < kMaxVec; ++j) {
             const int i = lane + 64 * j;
-            xh[j] = gw[j] = rv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            xh[j] = gw[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (!gres || i >= nvec) rv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (i < nvec) {
-                const float4 xv = *reinterpret_cast<const float4 *>(x + row * C + 4 * i);
-                const bf16x4 g1 = ga ? *reinterpret_cast<const bf16x4 *>(ga + row * C + 4 * i) : bf16x4{};
-                const bf16x4 g2 = gb ? *reinterpret_cast<const bf16x4 *>(gb + row * C + 4 * i) : bf16x4{};
-                if (gres) rv[j] = *reinterpret_cast<const float4 *>(gres + row * C + 4 * i);
+                const float4 xv = xl[j];
+                bf16x4 g1 = g1l[j], g2 = g2l[j];
+                if (!ga) g1 = bf16x4{};
+                if (!gb) g2 = bf16x4{};
                 xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 const float a0 = (float)g1[0], a1 = (float)g1[1], a2 = (float)g1[2], a3 = (float)g1[3];
                 const float b0 = (float)g2[0], b1 = (float)g2[1], b2 = (float)g2[2], b3 = (float)g2[3];
@@ -922,6 +942,7 @@ int vah_layernorm_dual_fwd(const float *x, const float *wa, const float *ba, con
                        (int)C, eps, (__bf16 *)ya, (__bf16 *)yb, mean, rstd)
     if (C <= 256) VAH_LND_FWD(1);
     else if (C <= 512) VAH_LND_FWD(2);
+    else if (C <= 768) VAH_LND_FWD(3);
     else VAH_LND_FWD(4);
 #undef VAH_LND_FWD
     return check_launch(fn);
@@ -954,6 +975,7 @@ int vah_layernorm_dual_bwd(const float *x, const void *ga, const void *gb, const
                        (const __bf16 *)gb, wa, wb, mean, rstd, gres, rows, (int)C, dx, ws)
     if (C <= 256) VAH_LND_BWD(1);
     else if (C <= 512) VAH_LND_BWD(2);
+    else if (C <= 768) VAH_LND_BWD(3);
     else VAH_LND_BWD(4);
 #undef VAH_LND_BWD
     // partial row = [dwa | dba | dwb | dbb] = the layout of dparams
