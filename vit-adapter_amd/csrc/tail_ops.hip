@@ -418,9 +418,13 @@ __global__ __launch_bounds__(256) void transpose_tokens_kernel(const void *__res
     const int64_t plane_base = (int64_t)b * C * T;
     if (TO_PLANES) {
         const float *tok = reinterpret_cast<const float *>(src) + tok_off;
+        float v4[4];                                                  // 4 clamped loads in flight, selected afterwards
 #pragma unroll
-        for (int r = ly; r < 32; r += 8)                              // tile[token][channel], channel fastest
-            tile[r][lx] = (tt + r < T && cc + lx < C) ? tok[(int64_t)(tt + r) * C + cc + lx] : 0.f;
+        for (int u = 0; u < 4; ++u)                                   // tile[token][channel], channel fastest
+            v4[u] = tok[(int64_t)min(tt + ly + 8 * u, T - 1) * C + min(cc + lx, C - 1)];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tile[ly + 8 * u][lx] = (tt + ly + 8 * u < T && cc + lx < C) ? v4[u] : 0.f;
         __syncthreads();
 #pragma unroll
         for (int r = ly; r < 32; r += 8)                              // write plane rows: token fastest
@@ -430,15 +434,21 @@ __global__ __launch_bounds__(256) void transpose_tokens_kernel(const void *__res
                 else reinterpret_cast<float *>(dst)[o] = tile[lx][r];
             }
     } else {
+        float v4[4];
+        int64_t o4[4];
 #pragma unroll
-        for (int r = ly; r < 32; r += 8) {                            // tile[channel][token], token fastest
-            float v = 0.f;
-            if (cc + r < C && tt + lx < T) {
-                const int64_t o = plane_base + (int64_t)(cc + r) * T + tt + lx;
-                v = planes_bf16 ? (float)reinterpret_cast<const __bf16 *>(src)[o] : reinterpret_cast<const float *>(src)[o];
-            }
-            tile[r][lx] = v;
+        for (int u = 0; u < 4; ++u)                                   // tile[channel][token], token fastest
+            o4[u] = plane_base + (int64_t)min(cc + ly + 8 * u, C - 1) * T + min(tt + lx, T - 1);
+        if (planes_bf16) {                                            // dtype branch around the 4 loads, not inside
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v4[u] = (float)reinterpret_cast<const __bf16 *>(src)[o4[u]];
+        } else {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v4[u] = reinterpret_cast<const float *>(src)[o4[u]];
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) tile[ly + 8 * u][lx] = (cc + ly + 8 * u < C && tt + lx < T) ? v4[u] : 0.f;
         __syncthreads();
         float *tok = reinterpret_cast<float *>(dst) + tok_off;
         const float add = (vec && cc + lx < C) ? vec[cc + lx] : 0.f;
@@ -461,23 +471,27 @@ __global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const __bf16 *__res
     if (ox >= Wo || oy >= Ho) return;
     const int64_t plane = blockIdx.z;
     const __bf16 *xp = x + plane * H * W;
+    // the 9 window values are requested together (clamped coordinates), validity applied afterwards: loads
+    // under `if (inside)` were waited on one by one
+    float win[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const int iy = min(max(2 * oy - 1 + k / 3, 0), H - 1), ix = min(max(2 * ox - 1 + k % 3, 0), W - 1);
+        win[k] = (float)xp[(int64_t)iy * W + ix];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     float best = -INFINITY;
     int pos = 0;
     bool any = false;
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = 2 * oy - 1 + ky;
-        if (iy < 0 || iy >= H) continue;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = 2 * ox - 1 + kx;
-            if (ix < 0 || ix >= W) continue;
-            const float v = (float)xp[(int64_t)iy * W + ix];
-            if (!any || v > best || v != v) {
-                best = v;
-                pos = ky * 3 + kx;
-                any = true;
-            }
+    for (int k = 0; k < 9; ++k) {
+        const int iy = 2 * oy - 1 + k / 3, ix = 2 * ox - 1 + k % 3;
+        const bool in = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        const float v = win[k];
+        if (in && (!any || v > best || v != v)) {
+            best = v;
+            pos = k;
+            any = true;
         }
     }
     const int64_t o = (plane * Ho + oy) * Wo + ox;
