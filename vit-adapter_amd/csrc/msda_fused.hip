@@ -15,6 +15,7 @@
 //
 // Restrictions of this path: D == 32, (L, P) in {(1,4), (3,4), (4,4)}, reference points shared by
 // the batch with last dim 2 (the adapter's).  Everything else uses the unfused Function.
+#include <cstdlib>
 #include <type_traits>
 
 #include "msda_common.h"
@@ -624,7 +625,7 @@ typedef __attribute__((__vector_size__(16 * sizeof(float)))) float df32x16;
 // quarter t & 3 of the candidate's grad_out row: everything it needs hangs off ONE candidate id, so
 // a chunk costs one dependent global-load latency (the id of the NEXT chunk is fetched a chunk
 // ahead), and at 22 KB of LDS seven workgroups per CU overlap their chunks.
-template <typename PT, int L, int P>
+template <typename PT, int L, int P, bool kCompact>
 __global__ __launch_bounds__(256) void msda_fused_bwd_gv_mfma(
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi, const PT *__restrict__ off,
     const PT *__restrict__ logit, const float *__restrict__ ref, int ref_levels,
@@ -634,6 +635,12 @@ __global__ __launch_bounds__(256) void msda_fused_bwd_gv_mfma(
     constexpr int LP = L * P;
     __shared__ __attribute__((aligned(16))) float s_w[64 * kDenseWS];
     __shared__ __attribute__((aligned(16))) __bf16 s_gt[kD * kDenseGS];
+    // kCompact: only ~20 % of a tile's candidates put a corner into the tile.  A cheap first pass (one
+    // thread per candidate: its 4 offsets of this level + the reference point, 24 of the 100 bytes a
+    // candidate costs below) keeps the candidates that do, compacted in candidate order into s_hit; the
+    // chunk body then runs over hits only: ~5x fewer grad_out row loads, W builds and MFMA slabs.
+    __shared__ int s_hit[kCompact ? 64 + 256 : 1];
+    __shared__ int s_cnt[2][4];
 
     // tile-major order: the host sorts the tiles by candidate count, so the long ones start first
     const int64_t b = blockIdx.x;
@@ -654,12 +661,66 @@ __global__ __launch_bounds__(256) void msda_fused_bwd_gv_mfma(
         df32x16 acc;
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-        int q_next = ci < tm.cand_count ? cand[tm.cand_start + ci] : -1;
-        for (int c0 = 0; c0 < tm.cand_count; c0 += kDenseKC) {
-            int q = q_next;
-            if (q < 0 || q >= Lq) q = -1;
-            const int nxt = c0 + kDenseKC + ci;
-            q_next = nxt < tm.cand_count ? cand[tm.cand_start + nxt] : -1;
+        int q_next = (!kCompact && ci < tm.cand_count) ? cand[tm.cand_start + ci] : -1;
+        int qa_next = (kCompact && tid < tm.cand_count) ? cand[tm.cand_start + tid] : -1;      // one pass ahead
+        int c0 = 0, nhit = 0, pass = 0;                 // uniform over the workgroup
+        for (;;) {
+            int q;
+            if constexpr (kCompact) {
+                // ---- first pass: top the hit list up to one chunk (64) or the end of the candidates
+                while (nhit < kDenseKC && c0 < tm.cand_count) {
+                    int qa = qa_next;
+                    if (qa < 0 || qa >= Lq) qa = -1;
+                    {
+                        const int nx = c0 + 256 + tid;
+                        qa_next = nx < tm.cand_count ? cand[tm.cand_start + nx] : -1;
+                    }
+                    bool hit = false;
+                    if (qa >= 0) {
+                        const int64_t rowa = (n * Lq + qa) * M + m;
+                        const float2 rpa = *reinterpret_cast<const float2 *>(
+                            ref + ((int64_t)qa * ref_levels + (ref_levels > 1 ? l : 0)) * 2);
+                        float2 oa[P];
+#pragma unroll
+                        for (int u = 0; u < P; ++u) oa[u] = load2(off + (rowa * LP + l * P + u) * 2);
+#pragma unroll
+                        for (int u = 0; u < P; ++u) {          // the chunk body's own arithmetic: an exact filter
+                            if (!(fabsf(oa[u].x) <= near_radius && fabsf(oa[u].y) <= near_radius)) continue;
+                            const float lxa = rpa.x + oa[u].x / (float)lv.W, lya = rpa.y + oa[u].y / (float)lv.H;
+                            const float h_im = lya * (float)lv.H - 0.5f, w_im = lxa * (float)lv.W - 0.5f;
+                            if (!(h_im > -1.f && w_im > -1.f && h_im < (float)lv.H && w_im < (float)lv.W)) continue;
+                            const int ry0 = (int)floorf(h_im) - tm.y0, rx0 = (int)floorf(w_im) - tm.x0;
+                            const bool yin = (ry0 >= 0 && ry0 < tm.ny) || (ry0 + 1 >= 0 && ry0 + 1 < tm.ny);
+                            const bool xin = (rx0 >= 0 && rx0 < tm.nx) || (rx0 + 1 >= 0 && rx0 + 1 < tm.nx);
+                            hit = hit || (yin && xin);
+                        }
+                    }
+                    const unsigned long long bal = __ballot(hit);
+                    if (lane == 0) s_cnt[pass & 1][wv] = __popcll(bal);
+                    __syncthreads();
+                    int base = nhit, total = 0;
+#pragma unroll
+                    for (int w2 = 0; w2 < 4; ++w2) {
+                        const int cw = s_cnt[pass & 1][w2];
+                        base += w2 < wv ? cw : 0;
+                        total += cw;
+                    }
+                    if (hit) s_hit[base + __popcll(bal & ((1ull << lane) - 1ull))] = qa;
+                    nhit += total;
+                    c0 += 256;
+                    ++pass;
+                }
+                if (nhit == 0) break;                    // list drained and no candidates left
+                __syncthreads();                         // the hits are visible
+                q = ci < min(nhit, kDenseKC) ? s_hit[ci] : -1;
+            } else {
+                if (c0 >= tm.cand_count) break;
+                q = q_next;
+                if (q < 0 || q >= Lq) q = -1;
+                const int nxt = c0 + kDenseKC + ci;
+                q_next = nxt < tm.cand_count ? cand[tm.cand_start + nxt] : -1;
+                c0 += kDenseKC;
+            }
             // ---- issue every load of this thread's (candidate, point) at once
             const int64_t row = (n * Lq + max(q, 0)) * M + m;
             const dbf16x8 gq = *reinterpret_cast<const dbf16x8 *>(grad_out + row * kD + p * 8);
@@ -729,6 +790,14 @@ __global__ __launch_bounds__(256) void msda_fused_bwd_gv_mfma(
                 }
             }
             __syncthreads();
+            if constexpr (kCompact) {                    // drop the processed chunk from the hit list
+                const int rest = max(nhit - kDenseKC, 0);          // <= 255
+                const int keep = tid < rest ? s_hit[kDenseKC + tid] : 0;
+                __syncthreads();
+                if (tid < rest) s_hit[tid] = keep;
+                nhit = rest;
+                // (the next top-up pass or chunk starts with a barrier of its own before s_hit is read)
+            }
         }
         // ---- one 128-byte atomic per pixel row and wave: lane = channel r, registers = pixel rows
         {
@@ -799,10 +868,20 @@ int launch_bwd(const FusedArgs &a) {
     if (gblocks >= ((int64_t)1 << 31)) return fail(VAH_E_SHAPE, "msda fused backward: tile grid too large");
     if (a.cap == 0) {                            // dense pull on the matrix cores (bf16 grad_out rows only)
         if constexpr (std::is_same<VT, __bf16>::value) {
-            hipLaunchKernelGGL((msda_fused_bwd_gv_mfma<PT, L, P>), dim3((unsigned)gblocks), dim3(256), 0, a.st, a.shapes,
-                               a.lsi, (const PT *)a.off, (const PT *)a.logit, a.ref, a.ref_levels,
-                               (const __bf16 *)a.grad_out, a.tile_meta, a.cand, (int)a.ntiles, a.S, (int)a.M, a.Lq,
-                               a.near_radius, a.grad_value);
+            static const bool compact = [] {
+                const char *e = getenv("VAH_MSDA_PULL_COMPACT");
+                return !(e && e[0] == '0');
+            }();
+            if (compact)
+                hipLaunchKernelGGL((msda_fused_bwd_gv_mfma<PT, L, P, true>), dim3((unsigned)gblocks), dim3(256), 0, a.st,
+                                   a.shapes, a.lsi, (const PT *)a.off, (const PT *)a.logit, a.ref, a.ref_levels,
+                                   (const __bf16 *)a.grad_out, a.tile_meta, a.cand, (int)a.ntiles, a.S, (int)a.M, a.Lq,
+                                   a.near_radius, a.grad_value);
+            else
+                hipLaunchKernelGGL((msda_fused_bwd_gv_mfma<PT, L, P, false>), dim3((unsigned)gblocks), dim3(256), 0, a.st,
+                                   a.shapes, a.lsi, (const PT *)a.off, (const PT *)a.logit, a.ref, a.ref_levels,
+                                   (const __bf16 *)a.grad_out, a.tile_meta, a.cand, (int)a.ntiles, a.S, (int)a.M, a.Lq,
+                                   a.near_radius, a.grad_value);
             return check_launch("msda fused backward (dense pull) launch");
         } else {
             return fail(VAH_E_UNSUPPORTED, "msda fused backward: the dense pull (cap_entries = 0) needs bf16 values");
