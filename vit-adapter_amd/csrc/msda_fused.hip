@@ -275,8 +275,15 @@ struct TapL {
     int pad;
 };
 
+#ifndef VAH_BWDA_WAVES1
+#define VAH_BWDA_WAVES1 1          // waves per SIMD asked for msda_fused_bwd_vec4 at L == 1 / L > 1
+#endif
+#ifndef VAH_BWDA_WAVESN
+#define VAH_BWDA_WAVESN 1
+#endif
 template <typename VT, typename PT, int L, int P>
-__global__ __launch_bounds__(kBlock) void msda_fused_bwd_vec4(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(L == 1 ? VAH_BWDA_WAVES1 : VAH_BWDA_WAVESN)))
+void msda_fused_bwd_vec4(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const PT *__restrict__ off, const PT *__restrict__ logit, const float *__restrict__ ref,
     int ref_levels, const VT *__restrict__ grad_out, int64_t S, int M, int64_t Lq, int64_t total_rows,
@@ -625,8 +632,12 @@ typedef __attribute__((__vector_size__(16 * sizeof(float)))) float df32x16;
 // quarter t & 3 of the candidate's grad_out row: everything it needs hangs off ONE candidate id, so
 // a chunk costs one dependent global-load latency (the id of the NEXT chunk is fetched a chunk
 // ahead), and at 22 KB of LDS seven workgroups per CU overlap their chunks.
+#ifndef VAH_PULL_WAVES
+#define VAH_PULL_WAVES 6           // waves per SIMD asked of the compiler for the dense pull kernel: <= 80 registers, six
+                                   // workgroups per CU (LDS allows six); 183 -> 172 us per backward call, A/B on one box
+#endif
 template <typename PT, int L, int P, bool kCompact>
-__global__ __launch_bounds__(256) void msda_fused_bwd_gv_mfma(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VAH_PULL_WAVES))) void msda_fused_bwd_gv_mfma(
     const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi, const PT *__restrict__ off,
     const PT *__restrict__ logit, const float *__restrict__ ref, int ref_levels,
     const __bf16 *__restrict__ grad_out, const int *__restrict__ tile_meta, const int *__restrict__ cand,
