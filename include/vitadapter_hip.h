@@ -150,8 +150,9 @@ int vah_msda_backward_win_f32(const float *value, const int64_t *shapes, const i
  * the others are scattered with per-sample atomics as without a schedule.  cap_entries = capacity of
  * the per-workgroup record store (10 bytes each, <= 150 KiB, even, < 65536); overflow falls back to
  * atomics, as does the whole pass when N*Lq*M >= 2^24.
- * cap_entries = 0 selects the DENSE form (bf16 values only): per tile and chunk of 128 candidates the
- * in-tile (attention x bilinear) weights are added into a dense (64 pixels x 128 queries) matrix in
+ * cap_entries = 0 selects the DENSE form (bf16 values only): the candidates that put a corner into the
+ * tile are compacted first (their offsets and reference point only); per tile and chunk of 64 of these
+ * the in-tile (attention x bilinear) weights are added into a dense (64 pixels x 64 queries) matrix in
  * LDS and multiplied with the staged grad_out rows on the matrix cores (weights as bf16 hi + lo,
  * fp32 accumulation) - no records, no sort, no per-record row gather; tiles should be 8 x 8
  * (larger ones are processed in 64-pixel slabs).  The
