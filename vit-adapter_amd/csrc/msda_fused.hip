@@ -276,13 +276,13 @@ struct TapL {
 };
 
 #ifndef VAH_BWDA_WAVES1
-#define VAH_BWDA_WAVES1 1          // waves per SIMD asked for msda_fused_bwd_vec4 at L == 1 / L > 1
-#endif
+#define VAH_BWDA_WAVES1 6          // waves per SIMD asked for msda_fused_bwd_vec4 at L == 1 / L > 1 (80 / 168 registers):
+#endif                             // msda_fused_bwd 170.5 -> 167.7 us per call, A/B of two builds on one box
 #ifndef VAH_BWDA_WAVESN
-#define VAH_BWDA_WAVESN 1
+#define VAH_BWDA_WAVESN 3
 #endif
 template <typename VT, typename PT, int L, int P>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(L == 1 ? VAH_BWDA_WAVES1 : VAH_BWDA_WAVESN)))
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(sizeof(VT) == 2 ? (L == 1 ? VAH_BWDA_WAVES1 : VAH_BWDA_WAVESN) : 1)))   // fp32 values would spill
 void msda_fused_bwd_vec4(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
     const PT *__restrict__ off, const PT *__restrict__ logit, const float *__restrict__ ref,
