@@ -512,29 +512,38 @@ __global__ __launch_bounds__(256) void maxpool3s2_bwd_kernel(const __bf16 *__res
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const int oy0 = iy >> 1, oy1 = (iy + 1) >> 1;                  // the one or two window rows that contain iy
     const int oxb = ix0 >> 1;                                       // windows oxb .. oxb + 4 touch these 8 columns
+    // all 20 loads (2 window rows x 5 windows x {gradient, recorded position}) are requested first, with
+    // clamped coordinates; validity is applied afterwards (loads under `in ? .. : ..` were waited on in pairs)
+    float g[2][5];
+    int p[2][5];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int oyc = min(a == 0 ? oy0 : oy1, Ho - 1);
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            const int64_t at = (int64_t)oyc * Wo + min(oxb + u, Wo - 1);
+            g[a][u] = (float)gp[at];
+            p[a][u] = (int)ip[at];
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
         const int oy = a == 0 ? oy0 : oy1;
         if ((a == 1 && oy1 == oy0) || oy >= Ho) continue;
         const int ky3 = (iy - (2 * oy - 1)) * 3;
-        float g[5];
-        int p[5];
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
-            const int ox = oxb + u;
-            const bool in = ox < Wo;
-            g[u] = in ? (float)gp[(int64_t)oy * Wo + ox] : 0.f;
-            p[u] = in ? (int)ip[(int64_t)oy * Wo + ox] : -1;
-        }
+        for (int u = 0; u < 5; ++u)
+            if (oxb + u >= Wo) p[a][u] = -1;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             // column ix0 + e lies in window (ix0 + e) >> 1 at kx = 1 (even e) or 2 (odd e), and in the next
             // window at kx = 0 (odd e only); ix0 is a multiple of 8
             const int u0 = e >> 1;
             const int kx0 = (e & 1) ? 2 : 1;
-            if (p[u0] == ky3 + kx0) acc[e] += g[u0];
+            if (p[a][u0] == ky3 + kx0) acc[e] += g[a][u0];
             if (e & 1)
-                if (p[u0 + 1] == ky3 + 0) acc[e] += g[u0 + 1];
+                if (p[a][u0 + 1] == ky3 + 0) acc[e] += g[a][u0 + 1];
         }
     }
     __bf16 *o = gx + (plane * H + iy) * (int64_t)W + ix0;
