@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
     // every load of the row is requested before the first is used: with the residual operands read
     // under `if (res.z)` inside the slot loop each slot waited for its own x / z / gamma round trip
     bf16x4 zv[kMaxVec];
-    float4 gm[kMaxVec];
+    float4 gm[kMaxVec], wv4[kMaxVec], bv4[kMaxVec];
     float sb = 1.f;
     if constexpr (kRes) sb = res.sc ? res.sc[row / res.rows_per_batch] : 1.f;
 #pragma unroll
@@ -67,6 +67,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
             gm[j] = make_float4(1.f, 1.f, 1.f, 1.f);
             if (res.gamma) gm[j] = *reinterpret_cast<const float4 *>(res.gamma + 4 * i);
         }
+        wv4[j] = *reinterpret_cast<const float4 *>(w + 4 * i);      // affine parameters too: their latency hides
+        bv4[j] = *reinterpret_cast<const float4 *>(b + 4 * i);      // behind the two reductions
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -101,8 +103,7 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float *__restrict__ x
     for (int j = 0; j < kMaxVec; ++j) {
         const int i = lane + 64 * j;
         if (i < nvec) {
-            const float4 ww = *reinterpret_cast<const float4 *>(w + 4 * i);
-            const float4 bb = *reinterpret_cast<const float4 *>(b + 4 * i);
+            const float4 ww = wv4[j], bb = bv4[j];
             bf16x4 o;
             o[0] = (__bf16)((v[j].x - mu) * rs * ww.x + bb.x);
             o[1] = (__bf16)((v[j].y - mu) * rs * ww.y + bb.y);
