@@ -1,20 +1,28 @@
 #!/usr/bin/env python
 """bench.py -- ViT-Adapter-B 1024x1024 training step throughput on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 One process per GPU; data parallel over RCCL (torch DDP, gradient all-reduce overlapped with
 backward, SyncBatchNorm statistics exchanged per layer).  A "step" is one full pass of the hot
-path over one synthetic batch: zero_grad -> ViTAdapter forward (bf16 autocast, deformable
-attention in fp32 on the HIP kernels) -> loss = sum_k mean(f_k) -> backward (+ gradient
-all-reduce) -> fused AdamW update.  Inputs are resident in HBM before the timed region.
+path over one synthetic batch: zero_grad -> ViTAdapter forward under bf16 autocast (the fused
+MSDeformAttn core runs on bf16 values / offsets / logits with fp32 accumulation, the ViT attention on
+bf16 MFMA tiles) -> loss = sum_k mean(f_k) -> backward (+ gradient all-reduce) -> fused AdamW
+update.  Inputs are resident in HBM before the timed region.
 
 Rank 0 prints ONE JSON line with the contract fields plus
-  "roofline":     the MSDA kernel with the largest total time in the timed region: algorithmic
-                  bytes per launch / mean launch duration (HIP events recorded by the library on
-                  the launch stream during the timed steps) against the 8 TB/s HBM3E peak
+  "roofline":     the MSDA entry point with the largest total time in the timed region: bytes the
+                  launch must move FOR THE DTYPES IT RUNS WITH / mean launch duration (HIP events
+                  recorded by the library on the launch stream during the timed steps) against the
+                  8 TB/s HBM3E peak; the op's fp32-definition bytes are reported
+                  beside it as `frac_fp32_definition`, never as `frac`
+  "kernels":      every timed entry point: the fused MSDA core and the ViT attention kernels
+                  (bound "mfma": 4*B*heads*N^2*64 flops per forward launch against the 2.5 PFLOP/s
+                  dense bf16 peak) inside the timed region, and - measured after it, same process -
+                  the reference-precision boundary kernels (plain fp32 MSDeformAttnFunction
+                  forward / backward at the BASELINE call shapes: cfg3 injector, cfg3 extractor, cfg1)
   "cpu_baseline": the oracle restatement of the same backbone (oracle/vit_adapter_ref.py, kind
                   "port") run fwd+bwd on the host cores on a bounded sample (one image), plus the
                   reference's pure-PyTorch MSDA core on BASELINE config 1.
@@ -33,6 +41,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK = 8.0e12     # B/s, MI355X_MICROARCH.md "HBM3E peak BW" (spec)
+MFMA_PEAK = 2.5e15    # flop/s, dense bf16 MFMA (same guide; the 5 PF headline includes 2:1 sparsity)
 
 
 def parse():
@@ -50,9 +59,16 @@ def parse():
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' lets several ranks share one GPU for a functional rehearsal of the "
                          "N>1 path on a 1-GPU box (not a performance mode)")
-    ap.add_argument('--profile-kernels', default='msda_',
+    ap.add_argument('--profile-kernels', default='msda_,attn_',
                     help='HIP-event timing inside the timed region for the library entry points whose name '
-                         'starts with this prefix ("" = all of them, costs ~2 %%; "none" = no events)')
+                         'starts with one of these comma-separated prefixes ("" = all of them, costs ~2 %%; '
+                         '"none" = no events)')
+    ap.add_argument('--boundary-iters', type=int, default=20,
+                    help='iterations of the fp32 boundary-kernel measurement after the timed region (0 = skip)')
+    ap.add_argument('--mock-step', action='store_true',
+                    help='CPU rehearsal of the launch path only (rank spawn, process group over gloo, barrier, '
+                         'max-over-ranks, the one JSON line) around a toy step; used by tests/test_bench_launch_cpu.py, '
+                         'never a measurement')
     ap.add_argument('--gemm-tuning', default='file', choices=['file', 'off', 'tune'],
                     help="hipBLASLt/rocBLAS solution selection through torch TunableOp: 'file' loads the "
                          "committed selections (no tuning at run time), 'tune' re-tunes and rewrites them")
@@ -96,23 +112,127 @@ def setup_gemm_tuning(args):
             tunable.read_file(TUNING_FILE)
 
 
+MSDA_SOURCES = ('msda.hip', 'msda_fused.hip', 'msda_tile.hip', 'msda_common.h')
+
+
+def msda_source_digest():
+    """sha1 over the MSDA kernel sources: stamps a PMC pass with the code it measured."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in MSDA_SOURCES:
+        path = os.path.join(ROOT, 'vit-adapter_amd', 'csrc', f)
+        if os.path.exists(path):
+            h.update(open(path, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel, args, preset_kw):
-    """HBM bytes per launch of the dominant MSDA kernel from the committed PMC pass
-    (profiles/r01_msda_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
-    tools/prof_msda_single.py, gfx950 FETCH_SIZE x2 correction).  Only for the exact shapes that
-    pass measured (BASELINE configs[2]: 4 injector + 6 extractor calls per direction and step);
-    None otherwise."""
+    """HBM bytes per launch of the dominant MSDA entry point from the committed PMC pass
+    (profiles/r02_msda_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+    tools/prof_msda_single.py, gfx950 FETCH_SIZE x2 correction, written by tools/pmc_msda_summary.py
+    together with the digest of the kernel sources it measured).  Only for the exact shapes that
+    pass measured (BASELINE configs[2]: 4 injector + 6 extractor calls per direction and step) and
+    only while the kernel sources are the ones it measured; None (-> "traffic": null) otherwise."""
     if args.preset != 'base_det' or list(args.size) != [1024, 1024] or args.batch != 2:
         return None
-    path = os.path.join(ROOT, 'profiles', 'r01_msda_pmc.json')
+    path = os.path.join(ROOT, 'profiles', 'r02_msda_pmc.json')
     try:
         pmc = json.load(open(path))
+        if pmc.get('msda_source_digest') != msda_source_digest():
+            return None
         d = 'fwd' if 'fwd' in kernel else 'bwd'
         inj = pmc['cfg3_inj_' + d]['hbm_bytes_per_launch']
         ext = pmc['cfg3_ext_' + d]['hbm_bytes_per_launch']
         return int((4 * inj + 6 * ext) / 10)
     except (OSError, KeyError, ValueError):
         return None
+
+
+# MSDeformAttnFunction call shapes of the BASELINE configs (SURVEY.md section 8 table):
+# name -> (N, M, D, P, Lq, value level shapes, query grid shapes)
+BOUNDARY_SHAPES = {
+    'cfg3_inj': (2, 12, 32, 4, 4096, [(128, 128), (64, 64), (32, 32)], [(64, 64)]),
+    'cfg3_ext': (2, 12, 32, 4, 21504, [(64, 64)], [(128, 128), (64, 64), (32, 32)]),
+    'cfg1': (1, 8, 32, 4, 5440, [(64, 64), (32, 32), (16, 16), (8, 8)], [(64, 64), (32, 32), (16, 16), (8, 8)]),
+}
+
+
+def boundary_inputs(cfg, dev, seed=0):
+    """fp32 inputs of one plain MSDeformAttnFunction call, "adapter" locations: the pixel-centre
+    reference grid of the query maps + (ring bias (p+1)*dir_m + N(0,1) px) / (W_l, H_l)
+    (ref ops/modules/ms_deform_attn.py:64-75,117-119; adapter_modules.py:13-25)."""
+    import math
+    N, M, D, P, Lq, shapes, qshapes = BOUNDARY_SHAPES[cfg]
+    L, S = len(shapes), sum(h * w for h, w in shapes)
+    g = torch.Generator(device=dev).manual_seed(seed)
+    hw = torch.as_tensor(shapes, dtype=torch.long, device=dev)
+    lsi = torch.cat((hw.new_zeros((1,)), hw.prod(1).cumsum(0)[:-1]))
+    value = torch.randn(N, S, M, D, device=dev, generator=g)
+    attn = torch.softmax(torch.randn(N, Lq, M, L * P, device=dev, generator=g), -1).view(N, Lq, M, L, P)
+    pts = []
+    for h, w in qshapes:
+        ys = (torch.arange(h, dtype=torch.float32, device=dev) + 0.5) / h
+        xs = (torch.arange(w, dtype=torch.float32, device=dev) + 0.5) / w
+        gy, gx = torch.meshgrid(ys, xs, indexing='ij')
+        pts.append(torch.stack((gx.reshape(-1), gy.reshape(-1)), -1))
+    ref = torch.cat(pts, 0)
+    assert ref.shape[0] == Lq
+    th = torch.arange(M, dtype=torch.float32, device=dev) * (2.0 * math.pi / M)
+    d = torch.stack([th.cos(), th.sin()], -1)
+    d = (d / d.abs().max(-1, keepdim=True)[0]).view(M, 1, 1, 2).repeat(1, L, P, 1)
+    d = d * torch.arange(1, P + 1, dtype=torch.float32, device=dev).view(1, 1, P, 1)
+    off = d[None, None] + torch.randn(N, Lq, M, L, P, 2, device=dev, generator=g)
+    loc = ref[None, :, None, None, None, :] + off / hw.flip(-1).float()[None, None, None, :, None, :]
+    gout = torch.randn(N, Lq, M * D, device=dev, generator=g)
+    return value, hw, lsi, loc.contiguous(), attn.contiguous(), gout
+
+
+def boundary_kernels(dev, iters):
+    """The reference-precision boundary: plain fp32 ms_deform_attn_forward / _backward
+    of the drop-in extension module at the BASELINE call shapes, timed with the library's HIP events
+    on the launch stream.  This is BASELINE's "MSDeformAttn GB/s vs HBM peak" at the precision of
+    ref detection/ops/functions/ms_deform_attn_func.py:21 (custom_fwd casts to fp32)."""
+    import MultiScaleDeformableAttention as MSDA
+    import _vah
+    rows = {}
+    for cfg in BOUNDARY_SHAPES:
+        v, s, i, l, a, g = boundary_inputs(cfg, dev)
+        for _ in range(3):
+            MSDA.ms_deform_attn_forward(v, s, i, l, a, 64)
+            MSDA.ms_deform_attn_backward(v, s, i, l, a, g, 64)
+        torch.cuda.synchronize()
+        _vah.prof_enable(True, 'msda_fwd_f32,msda_bwd_f32')
+        for _ in range(iters):
+            MSDA.ms_deform_attn_forward(v, s, i, l, a, 64)
+            MSDA.ms_deform_attn_backward(v, s, i, l, a, g, 64)
+        torch.cuda.synchronize()
+        _vah.prof_enable(False)
+        for name, r in _vah.prof_report().items():
+            if r['calls']:
+                rows['%s[%s]' % (name, cfg)] = kernel_row(r, 1)
+        del v, s, i, l, a, g
+    return rows
+
+
+def kernel_row(r, steps):
+    """One `kernels` entry from a library profile record (see _vah.prof_report)."""
+    avg_s = r['total_ms'] * 1e-3 / r['calls']
+    row = {'calls_per_step': r['calls'] / steps, 'avg_us': round(avg_s * 1e6, 2),
+           'ms_per_step': round(r['total_ms'] / steps, 3)}
+    if r['flops']:
+        fl = r['flops'] / r['calls']
+        row.update({'bound': 'mfma', 'flops_per_launch': int(fl),
+                    'achieved_TFLOPs': round(fl / avg_s / 1e12, 1),
+                    'frac_of_mfma_peak': round(fl / avg_s / MFMA_PEAK, 4)})
+    else:
+        per_launch, per_def = r['bytes'] / r['calls'], r['def_bytes'] / r['calls']
+        row.update({'bound': 'hbm', 'bytes_per_launch': int(per_launch),
+                    'achieved_GBps': round(per_launch / avg_s / 1e9, 1),
+                    'frac_of_hbm_peak': round(per_launch / avg_s / HBM_PEAK, 4)})
+        if per_def != per_launch:
+            row.update({'fp32_definition_bytes_per_launch': int(per_def),
+                        'frac_fp32_definition': round(per_def / avg_s / HBM_PEAK, 4)})
+    return row
 
 
 def cpu_baseline(args, preset_kw):
@@ -169,8 +289,57 @@ def cpu_baseline(args, preset_kw):
     return out
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start N ranks as a child
+    torch.distributed.run job (ref segmentation/dist_train.sh:8-9 does the same with
+    torch.distributed.launch) and relay its output.  Called before anything touches the GPU - a
+    process that has initialised HIP must not exec, and this one never does: it only waits."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return subprocess.run(cmd, env=env).returncode
+
+
+def main_mock(args):
+    """--mock-step: everything bench.py does around the step, on CPU over gloo, with a toy step."""
+    from vitadapter import data_parallel as dp
+    rank, _, world = dp.init_from_env('gloo')
+    assert world == args.gpus, '--gpus %d but the launcher started %d rank(s)' % (args.gpus, world)
+    dev = torch.device('cpu')
+    torch.manual_seed(0)
+    net = dp.wrap(torch.nn.Linear(8, 8), dev)
+    x = torch.randn(args.batch, 8, generator=torch.Generator().manual_seed(1234 + rank))
+    for _ in range(args.warmup):
+        net(x).sum().backward()
+    dp.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        net(x).sum().backward()
+    dp.barrier()
+    dt = dp.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        print(json.dumps({'metric': 'mock', 'value': round(world * args.batch * args.steps / dt, 3), 'unit': 'images/sec',
+                          'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'data': 'mock',
+                          'config': {'workload': 'mock step (launch-path rehearsal on CPU)', 'parallelism': 'dp%d' % world,
+                                     'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
+                                     'backend': 'gloo'}}), flush=True)
+    if world > 1:
+        dp.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
+    if args.mock_step:
+        return main_mock(args)
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     dev_index = local_rank % torch.cuda.device_count()
@@ -182,7 +351,7 @@ def main():
     from vitadapter.backbones.vit_adapter import PRESETS, ViTAdapter
 
     rank, local_rank, world = dp.init_from_env(args.backend)
-    assert world == args.gpus or world == 1, 'launch with torch.distributed.run for --gpus > 1'
+    assert world == args.gpus, '--gpus %d but the launcher started %d rank(s)' % (args.gpus, world)
 
     setup_gemm_tuning(args)
     preset_kw = dict(PRESETS[args.preset])
@@ -228,17 +397,7 @@ def main():
 
     if rank == 0:
         ips = world * args.batch * args.steps / dt
-        kernels = {}
-        for name, r in prof.items():
-            if r['calls'] == 0:
-                continue
-            avg_s = r['total_ms'] * 1e-3 / r['calls']
-            per_launch = r['bytes'] / r['calls']
-            kernels[name] = {'calls_per_step': r['calls'] / args.steps, 'avg_us': round(avg_s * 1e6, 2),
-                             'bytes_per_launch': int(per_launch),
-                             'achieved_GBps': round(per_launch / avg_s / 1e9, 1),
-                             'frac_of_hbm_peak': round(per_launch / avg_s / HBM_PEAK, 4),
-                             'ms_per_step': round(r['total_ms'] / args.steps, 3)}
+        kernels = {name: kernel_row(r, args.steps) for name, r in prof.items() if r['calls']}
         msda = {k: v for k, v in kernels.items() if k.startswith('msda_')}
         roofline = None
         if msda:
@@ -248,7 +407,12 @@ def main():
                         'unit': 'GB/s', 'frac': round(a / (HBM_PEAK / 1e9), 4),
                         'traffic': pmc_traffic(dom, args, preset_kw),
                         'avg_launch_us': msda[dom]['avg_us'],
-                        'algorithmic_bytes_per_launch': msda[dom]['bytes_per_launch']}
+                        'algorithmic_bytes_per_launch': msda[dom]['bytes_per_launch'],
+                        'bytes_are': 'moved for the IO dtypes of the launch (%s value / offsets / logits / grad_out, '
+                                     'fp32 grad_value)' % args.dtype,
+                        'frac_fp32_definition': msda[dom].get('frac_fp32_definition')}
+        if args.boundary_iters > 0 and world == 1:
+            kernels.update(boundary_kernels(dev, args.boundary_iters))
         line = {
             'metric': 'images/sec ViT-Adapter-B 1024x1024 fwd+bwd (+AdamW step)',
             'value': round(ips, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
@@ -261,7 +425,9 @@ def main():
                                        preset_kw['drop_path_rate'],
                                        'step = fwd+bwd' if args.no_optimizer else 'step = fwd+bwd+AdamW'),
                        'global_batch': world * args.batch, 'params_M': round(n_params / 1e6, 2),
-                       'parallelism': 'dp%d' % world},
+                       'parallelism': 'dp%d' % world,
+                       'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
+                       'backend': args.backend if world > 1 else None},
             'roofline': roofline,
             'kernels': kernels,
         }

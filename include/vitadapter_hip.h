@@ -385,11 +385,15 @@ int vah_dwconv3x3_tokens_wgrad_bf16(const void *x, const void *g, int64_t B, int
  * this library is bracketed by two hipEvents recorded on the launch's own stream.
  *   vah_prof_enable(1)  : start collecting (drops anything collected before)
  *   vah_prof_enable(0)  : stop collecting
- *   vah_prof_filter(p)  : time only the entry points whose name starts with p ("" = all); an
+ *   vah_prof_filter(p)  : time only the entry points whose name starts with p, or with one of the
+ *                         comma-separated prefixes in p ("" = all); an
  *                         event pair per launch is not free (about 2 % of a training step when every
  *                         entry point is timed), so a benchmark times the kernel it reports on
  *   vah_prof_report(..) : synchronises the recorded events and writes one text line per
- *                         kernel name:  "<name> <calls> <total_ms> <algorithmic_bytes>\n"
+ *                         kernel name:  "<name> <calls> <total_ms> <bytes> <def_bytes> <flops>\n"
+ *                         (bytes: algorithmic bytes for the IO dtypes the launches ran with; def_bytes:
+ *                         the operator's fp32-definition bytes; flops: matrix-core work,
+ *                         0 for the HBM-bound entry points)
  *                         into buf_host (NUL terminated); returns the number of bytes the
  *                         full report needs (call again with a bigger buffer if > cap).
  * ------------------------------------------------------------------------------------ */

@@ -1,0 +1,82 @@
+"""bf16 working copies of the fp32 Linear weights (vitadapter/fused.py::_Bf16Copies): a parameter
+written through `.data` (which does not bump Tensor._version: legacy optimizers, EMA hooks,
+`weight.data.normal_()` in the reference's _init_weights, ref segmentation/.../vit_adapter.py:61-74) must
+be seen by the next forward, and a copy saved for a backward must never change under it."""
+import pytest
+import torch
+
+from vitadapter import fused
+
+
+def test_copies_follow_data_writes_cpu():
+    cp = fused._Bf16Copies()
+    p = torch.nn.Parameter(torch.arange(8, dtype=torch.float32))
+    # outside a forward epoch every use casts afresh
+    a = cp.get(p)
+    p.data.mul_(2)                       # _version unchanged by construction of .data
+    b = cp.get(p)
+    assert torch.equal(b.float(), p.detach()) and not torch.equal(a, b)
+    # inside an epoch: one copy serves every use, made from the current values
+    cp.begin([p])
+    c1, c2 = cp.get(p), cp.get(p)
+    assert c1 is c2 and torch.equal(c1.float(), p.detach())
+    cp.end()
+    p.data.add_(1)
+    cp.begin([p])
+    c3 = cp.get(p)
+    assert torch.equal(c3.float(), p.detach())
+    assert torch.equal(c1.float(), p.detach() - 1), 'a copy handed out earlier must not be rewritten in place'
+    cp.end()
+    # after the epoch closes the stale epoch copy is not served
+    p.data.add_(1)
+    assert torch.equal(cp.get(p).float(), p.detach())
+
+
+@pytest.mark.gpu
+def test_fused_linear_sees_data_writes_gpu():
+    lin = torch.nn.Linear(64, 32).cuda()
+    pair_a, pair_b = torch.nn.Linear(64, 16).cuda(), torch.nn.Linear(64, 8).cuda()
+    x = torch.randn(128, 64, device='cuda')
+    holder = torch.nn.ModuleList([lin, pair_a, pair_b])
+
+    def run():
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            fused.refresh_linear_copies(holder)
+            try:
+                y = fused.linear(lin, x)
+                ya, yb = fused.linear_pair(pair_a, pair_b, x)
+            finally:
+                fused.end_forward()
+        return y.float(), ya.float(), yb.float()
+
+    y0, a0, b0 = run()
+    for m in (lin, pair_a, pair_b):
+        m.weight.data.mul_(2)
+        m.bias.data.zero_()
+    y1, a1, b1 = run()
+    for got, m in ((y1, lin), (a1, pair_a), (b1, pair_b)):
+        want = torch.nn.functional.linear(x, m.weight, m.bias)
+        assert (got - want).abs().max().item() <= 2e-2 * max(1.0, want.abs().max().item())
+    assert not torch.allclose(y0, y1)
+
+
+@pytest.mark.gpu
+def test_backward_uses_the_copy_of_its_own_forward_gpu():
+    """forward A, parameters change, forward B, then backward A: dX of A must use A's weights."""
+    lin = torch.nn.Linear(64, 32).cuda()
+    holder = torch.nn.ModuleList([lin])
+    x = torch.randn(16, 64, device='cuda', requires_grad=True)
+    w0 = lin.weight.detach().clone()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        fused.refresh_linear_copies(holder)
+        ya = fused.linear(lin, x)
+        fused.end_forward()
+        lin.weight.data.mul_(3)
+        fused.refresh_linear_copies(holder)
+        yb = fused.linear(lin, x.detach())
+        fused.end_forward()
+    g = torch.randn_like(ya)
+    (gx,) = torch.autograd.grad(ya, x, g)
+    want = g.float() @ w0.to(torch.bfloat16).float()
+    assert (gx.float() - want).abs().max().item() <= 2e-2 * max(1.0, want.abs().max().item())
+    assert yb is not None

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -153,14 +153,17 @@ def prof_enable(on, prefix=''):
 
 
 def prof_report():
-    """-> {kernel_name: dict(calls, total_ms, bytes)}; synchronises the recorded events."""
+    """-> {kernel_name: dict(calls, total_ms, bytes, def_bytes, flops)}; synchronises the recorded events.
+    bytes = algorithmic bytes for the IO dtypes the launches ran with, def_bytes = the operator's
+    fp32-definition bytes, flops = matrix-core work (0 for the HBM-bound entry points)."""
     need = lib.vah_prof_report(None, 0)
     buf = ctypes.create_string_buffer(int(need) + 64)
     lib.vah_prof_report(buf, len(buf))
     out = {}
     for line in buf.value.decode().splitlines():
-        name, calls, ms, nbytes = line.split()
-        out[name] = dict(calls=int(calls), total_ms=float(ms), bytes=int(nbytes))
+        name, calls, ms, nbytes, dbytes, flops = line.split()
+        out[name] = dict(calls=int(calls), total_ms=float(ms), bytes=int(nbytes), def_bytes=int(dbytes),
+                         flops=int(flops))
     return out
 
 

@@ -379,13 +379,17 @@ static int attn_bwd_impl(const char *fn, const void *q, const void *k, const voi
     const float scale_log2 = scale * 1.4426950408889634f;
     const dim3 grid((unsigned)((N + 127) / 128), (unsigned)H, (unsigned)B);
     {
-        LaunchScope scope("attn_bwd_dq_bf16", 6 * B * H * N * kHD * 2, st);
+        // useful flops of the whole backward = 2.5x the forward (S, dP, dV, dK, dQ products); both kernels
+        // recompute S and dP: dq runs 3 products (6 B H N^2 64), dkdv 4 (8 B H N^2 64)
+        LaunchScope scope(rm.win ? "attn_win_bwd_dq_bf16" : "attn_bwd_dq_bf16", 6 * B * H * N * kHD * 2, st, 0,
+                          6 * B * H * N * N * kHD);
         hipLaunchKernelGGL(attn_bwd_dq_kernel, grid, dim3(256), 0, st, (const __bf16 *)q, (const __bf16 *)k,
                            (const __bf16 *)v, kt, (const __bf16 *)dout, ld, rm, ld_out, lse, delta,
                            (int)N, Np, (int)H, scale, scale_log2, (__bf16 *)dq, ld_d);
         if (int rc = check_launch(fn)) return rc;
     }
-    LaunchScope scope("attn_bwd_dkdv_bf16", 8 * B * H * N * kHD * 2, st);
+    LaunchScope scope(rm.win ? "attn_win_bwd_dkdv_bf16" : "attn_bwd_dkdv_bf16", 8 * B * H * N * kHD * 2, st, 0,
+                      8 * B * H * N * N * kHD);
     hipLaunchKernelGGL(attn_bwd_dkdv_kernel, grid, dim3(256), 0, st, (const __bf16 *)q, (const __bf16 *)k,
                        (const __bf16 *)v, qt, (const __bf16 *)dout, dot, ld, rm, ld_out, lse, delta,
                        (int)N, Np, (int)H, scale, scale_log2, (__bf16 *)dk, (__bf16 *)dv, ld_d);

@@ -254,7 +254,9 @@ static int attn_fwd_impl(const char *fn, const void *q, const void *k, const voi
     }
     const float scale_log2 = scale * 1.4426950408889634f;
     // algorithmic bytes: q, k, v read once, out written once (bf16) + lse
-    LaunchScope scope("attn_fwd_bf16", 4 * B * H * N * kHD * 2 + B * H * N * 4, st);
+    // flops: QK^T + PV = 4 * B * heads * N^2 * 64; windows: N = win^2 with the padded keys
+    LaunchScope scope(rm.win ? "attn_win_fwd_bf16" : "attn_fwd_bf16", 4 * B * H * N * kHD * 2 + B * H * N * 4, st, 0,
+                      4 * B * H * N * N * kHD);
     hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)((N + kQBlock - 1) / kQBlock), (unsigned)H, (unsigned)B),
                        dim3(256), 0, st, (const __bf16 *)q, (const __bf16 *)k, (const __bf16 *)vt_ws, ld,
                        rm, (int)N, Np, (int)H, scale_log2, (__bf16 *)out, ld_out, lse);

@@ -15,7 +15,10 @@ void clear_error();
 // kernel launch(es) issued while it is alive, on `stream`.
 class LaunchScope {
   public:
-    LaunchScope(const char *name, int64_t algorithmic_bytes, hipStream_t stream);
+    // algorithmic_bytes: what the launch must move for the IO dtypes it actually runs with;
+    // def_bytes: the same operator by its fp32 definition, 0 = same; flops: for MFMA-bound kernels.
+    LaunchScope(const char *name, int64_t algorithmic_bytes, hipStream_t stream, int64_t def_bytes = 0,
+                int64_t flops = 0);
     ~LaunchScope();
 
   private:
@@ -25,6 +28,10 @@ class LaunchScope {
 
 // Checks hipGetLastError() after a launch; returns 0 or the hipError_t (message stored).
 int check_launch(const char *what);
+
+// Raises a kernel's dynamic-LDS limit on the CURRENT device.  The attribute is per device (and cheap to
+// set), so it is set before every launch that needs it rather than once per process.
+int allow_dynamic_lds(const void *kernel, int bytes, const char *what);
 
 constexpr int kCUs = 256;   // MI355X: 8 XCDs x 32 CUs
 constexpr int kWave = 64;

@@ -29,18 +29,38 @@ int check_launch(const char *what) {
     return 0;
 }
 
+int allow_dynamic_lds(const void *kernel, int bytes, const char *what) {
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return fail((int)e, "%s: cannot allow %d bytes of dynamic LDS: %s", what, bytes, hipGetErrorString(e));
+    return 0;
+}
+
 // ---- launch timing -----------------------------------------------------------------
 struct Rec {
     const char *name;
-    int64_t bytes;
+    int64_t bytes, def_bytes, flops;
     hipEvent_t start, stop;
 };
 
 static std::mutex g_mu;
 static bool g_on = false;
-static char g_prefix[64] = "";                  // only scopes whose name starts with this are timed
+static char g_prefix[128] = "";                 // only scopes whose name starts with one of these are timed
 static std::vector<Rec> g_recs;                 // live records of the current collection
 static std::vector<hipEvent_t> g_pool;          // recycled events
+
+// g_prefix is a comma-separated list of name prefixes ("" = everything)
+static bool name_selected(const char *name) {
+    const char *p = g_prefix;
+    if (!*p) return true;
+    while (*p) {
+        const char *e = strchr(p, ',');
+        const size_t n = e ? (size_t)(e - p) : strlen(p);
+        if (n > 0 && strncmp(name, p, n) == 0) return true;
+        if (!e) break;
+        p = e + 1;
+    }
+    return false;
+}
 
 static hipEvent_t take_event() {
     if (!g_pool.empty()) {
@@ -61,12 +81,12 @@ static void recycle_all() {
     g_recs.clear();
 }
 
-LaunchScope::LaunchScope(const char *name, int64_t bytes, hipStream_t stream)
+LaunchScope::LaunchScope(const char *name, int64_t bytes, hipStream_t stream, int64_t def_bytes, int64_t flops)
     : slot_(-1), stream_(stream) {
     if (!g_on) return;
     std::lock_guard<std::mutex> lk(g_mu);
-    if (!g_on || strncmp(name, g_prefix, strlen(g_prefix)) != 0) return;
-    Rec r{name, bytes, take_event(), take_event()};
+    if (!g_on || !name_selected(name)) return;
+    Rec r{name, bytes, def_bytes ? def_bytes : bytes, flops, take_event(), take_event()};
     if (!r.start || !r.stop) return;
     (void)hipEventRecord(r.start, stream);
     g_recs.push_back(r);
@@ -83,7 +103,7 @@ LaunchScope::~LaunchScope() {
 
 extern "C" {
 
-int vah_abi_version(void) { return 25; }
+int vah_abi_version(void) { return 26; }
 
 const char *vah_last_error(void) { return vah::g_err; }
 
@@ -105,7 +125,7 @@ int64_t vah_prof_report(char *buf, int64_t cap) {
     struct Agg {
         int64_t calls = 0;
         double ms = 0;
-        int64_t bytes = 0;
+        int64_t bytes = 0, def_bytes = 0, flops = 0;
     };
     std::map<std::string, Agg> agg;
     for (auto &r : vah::g_recs) {
@@ -116,12 +136,15 @@ int64_t vah_prof_report(char *buf, int64_t cap) {
         a.calls += 1;
         a.ms += ms;
         a.bytes += r.bytes;
+        a.def_bytes += r.def_bytes;
+        a.flops += r.flops;
     }
     std::string out;
     char line[256];
     for (auto &kv : agg) {
-        snprintf(line, sizeof(line), "%s %lld %.6f %lld\n", kv.first.c_str(),
-                 (long long)kv.second.calls, kv.second.ms, (long long)kv.second.bytes);
+        snprintf(line, sizeof(line), "%s %lld %.6f %lld %lld %lld\n", kv.first.c_str(),
+                 (long long)kv.second.calls, kv.second.ms, (long long)kv.second.bytes,
+                 (long long)kv.second.def_bytes, (long long)kv.second.flops);
         out += line;
     }
     if (buf && cap > 0) {

@@ -1169,11 +1169,7 @@ int vah_dwconv3x3_tokens_wgrad_bf16(const void *x, const void *g, int64_t B, int
     if (nblocks < 1) nblocks = 1;
     const size_t smem = (size_t)slots * C * 10 * sizeof(float);
     if (smem > 150 * 1024) return fail(VAH_E_SHAPE, "%s: C too small for the LDS reduction layout", fn);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)dwconv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 512);
-        attr_set = true;
-    }
+    if (int rc = allow_dynamic_lds((const void *)dwconv_wgrad_kernel, 160 * 1024 - 512, fn)) return rc;
     LaunchScope scope("dwconv_tokens_wgrad", total_tok * C * 4, st);
     hipLaunchKernelGGL(dwconv_wgrad_kernel, dim3((unsigned)nblocks), dim3(256), smem, st,
                        (const __bf16 *)x, (const __bf16 *)g, mp, N, (int)C, total_tok, ws);

@@ -899,12 +899,8 @@ int launch_bwd(const FusedArgs &a) {
         }
     }
     const size_t smem = (size_t)a.cap * 10;      // records (8 B) + order (2 B)
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)msda_fused_bwd_gv<VT, PT, L, P>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
-    }
+    if (int rc = allow_dynamic_lds((const void *)msda_fused_bwd_gv<VT, PT, L, P>, 150 * 1024, "msda fused backward"))
+        return rc;
     hipLaunchKernelGGL((msda_fused_bwd_gv<VT, PT, L, P>), dim3((unsigned)gblocks), dim3(kGvThreads), smem, a.st,
                        a.shapes, a.lsi, (const PT *)a.off, (const PT *)a.logit, a.ref, a.ref_levels,
                        (const VT *)a.grad_out, a.tile_meta, a.cand, (int)a.ntiles, a.S, (int)a.M, a.Lq,
@@ -965,9 +961,12 @@ int vah_msda_fused_forward(const void *value, int value_dtype, const int64_t *sh
     a.value = value, a.off = offsets, a.logit = logits, a.shapes = shapes, a.lsi = lsi, a.ref = ref;
     a.ref_levels = (int)ref_levels, a.N = N, a.S = S, a.M = M, a.L = L, a.Lq = Lq, a.P = P, a.out = out;
     a.st = (hipStream_t)stream;
-    // algorithmic bytes by the op's fp32 definition, whatever the IO dtypes:
-    // keeps the roofline fraction comparable with the unfused kernels
-    LaunchScope scope("msda_fused_fwd", 4 * (N * S * M * D + 3 * N * Lq * M * L * P + N * Lq * M * D), a.st);
+    // algorithmic bytes the launch really moves: value / out in the value dtype, offsets (2) + logits (1)
+    // per sample in the parameter dtype; the op's fp32 definition is reported
+    // beside it as def_bytes
+    const int64_t vs = value_dtype == 1 ? 2 : 4, ps = param_dtype == 1 ? 2 : 4;
+    LaunchScope scope("msda_fused_fwd", vs * (N * S * M * D + N * Lq * M * D) + ps * 3 * N * Lq * M * L * P, a.st,
+                      4 * (N * S * M * D + 3 * N * Lq * M * L * P + N * Lq * M * D));
     return dispatch<false>(a, value_dtype, param_dtype);
 }
 
@@ -999,7 +998,11 @@ int vah_msda_fused_backward(const void *value, int value_dtype, const int64_t *s
     a.grad_out = grad_out, a.grad_value = grad_value, a.d_off = d_offsets, a.d_logit = d_logits;
     a.tile_meta = tile_meta, a.cand = cand, a.ntiles = ntiles, a.cap = cap_entries, a.near_radius = near_radius;
     a.st = (hipStream_t)stream;
-    LaunchScope scope("msda_fused_bwd", 4 * (2 * N * S * M * D + 6 * N * Lq * M * L * P + N * Lq * M * D), a.st);
+    // moved bytes: value + grad_out read in the value dtype, offsets / logits read and their gradients
+    // written in the parameter dtype, grad_value written in fp32 (its zero-fill is not counted)
+    const int64_t vs = value_dtype == 1 ? 2 : 4, ps = param_dtype == 1 ? 2 : 4;
+    LaunchScope scope("msda_fused_bwd", vs * (N * S * M * D + N * Lq * M * D) + 4 * N * S * M * D + ps * 6 * N * Lq * M * L * P,
+                      a.st, 4 * (2 * N * S * M * D + 6 * N * Lq * M * L * P + N * Lq * M * D));
     return dispatch<true>(a, value_dtype, param_dtype);
 }
 

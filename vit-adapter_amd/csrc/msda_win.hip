@@ -479,12 +479,7 @@ int vah_msda_forward_win_f32(const float *value, const int64_t *shapes, const in
     const int64_t grid = N * n_groups * M;
     if (grid >= (1LL << 31)) return fail(VAH_E_SHAPE, "%s: grid too large", fn);
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)msda_fwd_win, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024 - 512);
-        attr_set = true;
-    }
+    if (int rc = allow_dynamic_lds((const void *)msda_fwd_win, 160 * 1024 - 512, fn)) return rc;
     const int64_t bytes = 4 * (N * S * M * D + 3 * N * Lq * M * L * P + N * Lq * M * D);
     LaunchScope scope("msda_fwd_f32", bytes, st);
     hipLaunchKernelGGL(msda_fwd_win, dim3((unsigned)grid), dim3(kThreads), smem, st, value,
@@ -514,13 +509,9 @@ int vah_msda_backward_win_f32(const float *value, const int64_t *shapes, const i
     const int64_t grid = N * n_groups * M;
     if (grid >= (1LL << 31)) return fail(VAH_E_SHAPE, "%s: grid too large", fn);
     hipStream_t st = (hipStream_t)stream;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const int cap = 160 * 1024 - 512;
-        (void)hipFuncSetAttribute((const void *)msda_bwd_win<true>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        (void)hipFuncSetAttribute((const void *)msda_bwd_win<false>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
-        attr_set = true;
-    }
+    if (int rc = allow_dynamic_lds(stage ? (const void *)msda_bwd_win<true> : (const void *)msda_bwd_win<false>,
+                                   160 * 1024 - 512, fn))
+        return rc;
     const int64_t bytes = 4 * (2 * N * S * M * D + 6 * N * Lq * M * L * P + N * Lq * M * D);
     LaunchScope scope("msda_bwd_f32", bytes, st);
     if (stage)

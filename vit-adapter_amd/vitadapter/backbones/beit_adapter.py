@@ -62,7 +62,13 @@ class BEiTAdapter(BEiT):
             m._reset_parameters()
 
     def forward(self, x):
-        fused.refresh_linear_copies(self)
+        fused.refresh_linear_copies(self)      # bf16 copies of the Linear weights for THIS forward: one launch
+        try:
+            return self._forward(x)
+        finally:
+            fused.end_forward()
+
+    def _forward(self, x):
         deform_inputs1, deform_inputs2 = deform_inputs(x)
 
         # fused tail: the biases of spm.fc1 and self.up reach norm1 as a per-channel shift

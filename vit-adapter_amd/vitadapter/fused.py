@@ -173,55 +173,67 @@ def layer_norm_keep(norm, x, fan_out=False):
 # ---------------------------------------------------------------------------------------
 class _Bf16Copies:
     """bf16 working copies of fp32 parameters.  autocast makes the same copies, but one tiny cast
-    kernel per parameter per step (and one more per gradient on the way back); here every copy of
-    a model is refreshed by one multi-tensor launch after the optimizer has stepped
-    (``refresh``), and a parameter that was missed is refreshed on use."""
+    kernel per parameter per use (and one more per gradient on the way back).  Here a model's forward
+    opens an EPOCH (``begin_forward``): ONE multi-tensor cast writes fresh copies of all its Linear
+    parameters into one new flat buffer, and those copies serve every use until the forward ends
+    (``end_forward``).  Outside an epoch every use makes its own cast.
+
+    Nothing is keyed on ``Tensor._version``: in-place writes through ``.data`` (legacy optimizers,
+    EMA / fp16 hooks, ``weight.data.normal_()``) do not bump it, and a cached copy would silently go
+    stale.  Copies are never rewritten in place either, so a backward that saved one still sees the
+    values of its own forward whatever ran in between."""
 
     def __init__(self):
-        self.entries = {}          # id(param) -> [weakref(param), copy, version, data_ptr]
+        self.entries = {}          # id(param) -> (weakref(param), copy, epoch)
+        self.epoch = 0             # even: no forward open; odd: the open forward's epoch
 
     def get(self, p):
         e = self.entries.get(id(p))
-        if e is None or e[0]() is not p or e[3] != p.data_ptr() or e[1].device != p.device:
-            import weakref
-            e = [weakref.ref(p), p.detach().to(torch.bfloat16), p._version, p.data_ptr()]
-            self.entries[id(p)] = e
-            if len(self.entries) > 4096:           # drop entries of collected parameters
-                self.entries = {k: v for k, v in self.entries.items() if v[0]() is not None}
-        elif e[2] != p._version:
-            e[1].copy_(p.detach())
-            e[2] = p._version
-        return e[1]
+        if e is not None and e[2] == self.epoch and (self.epoch & 1) and e[0]() is p and e[1].device == p.device:
+            return e[1]
+        return p.detach().to(torch.bfloat16)
 
-    def refresh(self, params):
-        dst, src = [], []
-        for p in params:
-            e = self.entries.get(id(p))
-            if e is None or e[0]() is not p or e[3] != p.data_ptr() or e[1].device != p.device:
-                self.get(p)
-            elif e[2] != p._version:
-                dst.append(e[1])
-                src.append(p.detach())
-                e[2] = p._version
-        if dst:
-            torch._foreach_copy_(dst, src)
+    def begin(self, params):
+        import weakref
+        self.epoch += 1 if (self.epoch & 1) == 0 else 2          # a nested / aborted forward just opens a new epoch
+        if not params:
+            return
+        flat = torch.empty(sum(p.numel() for p in params), dtype=torch.bfloat16, device=params[0].device)
+        views = [v.view(p.shape) for v, p in zip(flat.split([p.numel() for p in params]), params)]
+        torch._foreach_copy_(views, [p.detach() for p in params])
+        if len(self.entries) > 4096:               # drop entries of collected parameters
+            self.entries = {k: v for k, v in self.entries.items() if v[0]() is not None}
+        for p, v in zip(params, views):
+            self.entries[id(p)] = (weakref.ref(p), v, self.epoch)
+
+    def end(self):
+        if self.epoch & 1:
+            self.epoch += 1
 
 
 BF16_COPIES = _Bf16Copies()
 
 
 def refresh_linear_copies(module):
-    """Call once per forward of a model: one multi-tensor cast refreshes the bf16 copies of all
-    its nn.Linear parameters that changed since the last call."""
+    """Call at the start of a model's forward (pair with ``end_forward`` in a finally block): one
+    multi-tensor cast makes the bf16 copies of all its fp32 nn.Linear parameters for this forward."""
     if not (ENABLED['linear'] and _bf16_autocast()):
         return
+    # the list is cached on the module; a parameter that is replaced later is simply not part of the
+    # bulk cast and gets its own cast on use (slower, never stale)
     params = module.__dict__.get('_vah_linear_params')
     if params is None:
         params = [p for m in module.modules() if isinstance(m, torch.nn.Linear)
-                  for p in (m.weight, m.bias) if p is not None and p.dtype == torch.float32]
+                  for p in (m.weight, m.bias) if p is not None]
         module.__dict__['_vah_linear_params'] = params
-    if params and params[0].is_cuda:
-        BF16_COPIES.refresh(params)
+    live = [p for p in params if p.dtype == torch.float32 and p.is_cuda]
+    if live:
+        BF16_COPIES.begin(live)
+
+
+def end_forward():
+    """Close the epoch opened by ``refresh_linear_copies``: later uses cast on their own."""
+    BF16_COPIES.end()
 
 
 _GEMM_WS_BYTES = 32 << 20
@@ -328,8 +340,7 @@ class _LinearBF16(torch.autograd.Function):
         x2 = x2.contiguous()
         wb = BF16_COPIES.get(weight)
         y = gemm_bf16(x2, wb, trans_b=True, bias=bias.detach() if bias is not None else None)
-        ctx.save_for_backward(x2)
-        ctx.wb = wb
+        ctx.save_for_backward(x2, wb)
         ctx.has_bias = bias is not None
         ctx.in_shape = x.shape
         ctx.in_dtype = x.dtype
@@ -337,8 +348,7 @@ class _LinearBF16(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        (x2,) = ctx.saved_tensors
-        wb = ctx.wb
+        x2, wb = ctx.saved_tensors
         N = wb.shape[0]
         g2 = g.reshape(-1, N)
         if g2.dtype != torch.bfloat16:
@@ -369,25 +379,25 @@ class _LinearBF16(torch.autograd.Function):
 
 class _PairCopies:
     """bf16 [Wa; Wb] (rows concatenated) and fp32 [ba; bb] of two Linear layers that read the same
-    input, rebuilt when either parameter has changed."""
+    input: built once per forward epoch (see _Bf16Copies), on every use outside one."""
 
     def __init__(self):
         self.entries = {}
 
     def get(self, a, b):
         key = (id(a.weight), id(b.weight))
-        ver = (a.weight._version, b.weight._version, a.bias._version, b.bias._version,
-               a.weight.data_ptr(), b.weight.data_ptr())
+        epoch = BF16_COPIES.epoch
         e = self.entries.get(key)
-        if e is None or e[0] != ver or e[1].device != a.weight.device:
-            with torch.no_grad():
-                w = torch.cat([a.weight.detach(), b.weight.detach()], 0).to(torch.bfloat16)
-                bias = torch.cat([a.bias.detach(), b.bias.detach()], 0).float()
-            e = (ver, w, bias)
-            if len(self.entries) > 1024:
-                self.entries.clear()
-            self.entries[key] = e
-        return e[1], e[2]
+        if e is not None and e[0] == epoch and (epoch & 1) and e[1].device == a.weight.device and e[3]() is a.weight:
+            return e[1], e[2]
+        import weakref
+        with torch.no_grad():
+            w = torch.cat([a.weight.detach(), b.weight.detach()], 0).to(torch.bfloat16)
+            bias = torch.cat([a.bias.detach(), b.bias.detach()], 0).float()
+        if len(self.entries) > 1024:
+            self.entries.clear()
+        self.entries[key] = (epoch, w, bias, weakref.ref(a.weight))
+        return w, bias
 
 
 PAIR_COPIES = _PairCopies()
@@ -410,15 +420,15 @@ class _LinearPairBF16(torch.autograd.Function):
         w, bias = pair
         y = gemm_bf16(x2, w, trans_b=True, bias=bias)
         na = wa.shape[0]
-        ctx.save_for_backward(x2)
-        ctx.w, ctx.na, ctx.in_shape, ctx.in_dtype = w, na, x.shape, x.dtype
+        ctx.save_for_backward(x2, w)
+        ctx.na, ctx.in_shape, ctx.in_dtype = na, x.shape, x.dtype
         lead = x.shape[:-1]
         return y[:, :na].contiguous().view(*lead, na), y[:, na:].contiguous().view(*lead, w.shape[0] - na)
 
     @staticmethod
     def backward(ctx, ga, gb):
-        (x2,) = ctx.saved_tensors
-        w, na = ctx.w, ctx.na
+        x2, w = ctx.saved_tensors
+        na = ctx.na
         nb = w.shape[0] - na
         R = x2.shape[0]
         g = torch.empty((R, na + nb), dtype=torch.bfloat16, device=x2.device)
@@ -472,14 +482,12 @@ class _Conv1x1BF16(torch.autograd.Function):
         out = torch.empty((B, Co, H, W), dtype=torch.bfloat16, device=x.device)
         for b in range(B):
             gemm_bf16(wb, x[b].view(Ci, H * W), out=out[b].view(Co, H * W))
-        ctx.save_for_backward(x)
-        ctx.wb = wb
+        ctx.save_for_backward(x, wb)
         return out
 
     @staticmethod
     def backward(ctx, g):
-        (x,) = ctx.saved_tensors
-        wb = ctx.wb
+        x, wb = ctx.saved_tensors
         B, Ci, H, W = x.shape
         Co = wb.shape[0]
         g = g.contiguous().to(torch.bfloat16)
