@@ -211,10 +211,9 @@ def test_linear_bf16_matches_autocast(shape, out_f, bias):
     # parameters updated in place (optimizer step): the bf16 copy follows
     with torch.no_grad():
         lin.weight.mul_(0.5)
-    fused.refresh_linear_copies(lin)
     with torch.autocast('cuda', dtype=torch.bfloat16):
-        fused.refresh_linear_copies(lin)
-        y2 = fused.linear(lin, x)
+        with fused.forward_epoch(lin):
+            y2 = fused.linear(lin, x)
         y2r = lin(x)
     _close(y2, y2r, 1e-2, 'y after update')
     assert fused.linear(lin, x.float()).dtype == torch.float32       # no autocast -> plain nn.Linear

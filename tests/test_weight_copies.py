@@ -40,13 +40,9 @@ def test_fused_linear_sees_data_writes_gpu():
     holder = torch.nn.ModuleList([lin, pair_a, pair_b])
 
     def run():
-        with torch.autocast('cuda', dtype=torch.bfloat16):
-            fused.refresh_linear_copies(holder)
-            try:
-                y = fused.linear(lin, x)
-                ya, yb = fused.linear_pair(pair_a, pair_b, x)
-            finally:
-                fused.end_forward()
+        with torch.autocast('cuda', dtype=torch.bfloat16), fused.forward_epoch(holder):
+            y = fused.linear(lin, x)
+            ya, yb = fused.linear_pair(pair_a, pair_b, x)
         return y.float(), ya.float(), yb.float()
 
     y0, a0, b0 = run()
@@ -68,13 +64,11 @@ def test_backward_uses_the_copy_of_its_own_forward_gpu():
     x = torch.randn(16, 64, device='cuda', requires_grad=True)
     w0 = lin.weight.detach().clone()
     with torch.autocast('cuda', dtype=torch.bfloat16):
-        fused.refresh_linear_copies(holder)
-        ya = fused.linear(lin, x)
-        fused.end_forward()
+        with fused.forward_epoch(holder):
+            ya = fused.linear(lin, x)
         lin.weight.data.mul_(3)
-        fused.refresh_linear_copies(holder)
-        yb = fused.linear(lin, x.detach())
-        fused.end_forward()
+        with fused.forward_epoch(holder):
+            yb = fused.linear(lin, x.detach())
     g = torch.randn_like(ya)
     (gx,) = torch.autograd.grad(ya, x, g)
     want = g.float() @ w0.to(torch.bfloat16).float()

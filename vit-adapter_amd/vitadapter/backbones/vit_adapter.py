@@ -117,11 +117,8 @@ class ViTAdapter(TIMMVisionTransformer):
         return c2 + self.level_embed[0], c3 + self.level_embed[1], c4 + self.level_embed[2]
 
     def forward(self, x):
-        fused.refresh_linear_copies(self)      # bf16 copies of the Linear weights for THIS forward: one launch
-        try:
+        with fused.forward_epoch(self):        # bf16 copies of the Linear weights for THIS forward: one launch
             return self._forward(x)
-        finally:
-            fused.end_forward()
 
     def _forward(self, x):
         deform_inputs1, deform_inputs2 = deform_inputs(x)

@@ -176,7 +176,7 @@ class _Bf16Copies:
     kernel per parameter per use (and one more per gradient on the way back).  Here a model's forward
     opens an EPOCH (``begin_forward``): ONE multi-tensor cast writes fresh copies of all its Linear
     parameters into one new flat buffer, and those copies serve every use until the forward ends
-    (``end_forward``).  Outside an epoch every use makes its own cast.
+    (``forward_epoch`` is the context manager around both).  Outside an epoch every use makes its own cast.
 
     Nothing is keyed on ``Tensor._version``: in-place writes through ``.data`` (legacy optimizers,
     EMA / fp16 hooks, ``weight.data.normal_()``) do not bump it, and a cached copy would silently go
@@ -214,26 +214,34 @@ class _Bf16Copies:
 BF16_COPIES = _Bf16Copies()
 
 
-def refresh_linear_copies(module):
-    """Call at the start of a model's forward (pair with ``end_forward`` in a finally block): one
-    multi-tensor cast makes the bf16 copies of all its fp32 nn.Linear parameters for this forward."""
-    if not (ENABLED['linear'] and _bf16_autocast()):
-        return
-    # the list is cached on the module; a parameter that is replaced later is simply not part of the
-    # bulk cast and gets its own cast on use (slower, never stale)
-    params = module.__dict__.get('_vah_linear_params')
-    if params is None:
-        params = [p for m in module.modules() if isinstance(m, torch.nn.Linear)
-                  for p in (m.weight, m.bias) if p is not None]
-        module.__dict__['_vah_linear_params'] = params
-    live = [p for p in params if p.dtype == torch.float32 and p.is_cuda]
-    if live:
-        BF16_COPIES.begin(live)
+class forward_epoch:
+    """``with fused.forward_epoch(model): ...`` around a model's forward: on entry ONE multi-tensor cast
+    makes the bf16 copies of all its fp32 nn.Linear parameters, which then serve every fused Linear of
+    this forward; on exit (also by an exception) the epoch closes and later uses cast on their own, so
+    a parameter written between two forwards - by any means, `.data` included - is always seen."""
 
+    def __init__(self, module):
+        self.module = module
 
-def end_forward():
-    """Close the epoch opened by ``refresh_linear_copies``: later uses cast on their own."""
-    BF16_COPIES.end()
+    def __enter__(self):
+        module = self.module
+        if not (ENABLED['linear'] and _bf16_autocast()):
+            return self
+        # the list is cached on the module; a parameter that is replaced later is simply not part of the
+        # bulk cast and gets its own cast on use (slower, never stale)
+        params = module.__dict__.get('_vah_linear_params')
+        if params is None:
+            params = [p for m in module.modules() if isinstance(m, torch.nn.Linear)
+                      for p in (m.weight, m.bias) if p is not None]
+            module.__dict__['_vah_linear_params'] = params
+        live = [p for p in params if p.dtype == torch.float32 and p.is_cuda]
+        if live:
+            BF16_COPIES.begin(live)
+        return self
+
+    def __exit__(self, *exc):
+        BF16_COPIES.end()
+        return False
 
 
 _GEMM_WS_BYTES = 32 << 20
