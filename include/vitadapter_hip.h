@@ -174,6 +174,39 @@ int vah_msda_fused_backward(const void *value, int value_dtype, const int64_t *s
                             float near_radius, int64_t cap_entries, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * TILED BACKWARD: grad_value without atomics and without a zero-fill, for ANY sampling locations
+ * (csrc/msda_tile.hip; replaces the scatter of ms_deform_im2col_cuda.cuh:87-159 as called from
+ * :301-403).  The samples are binned on the device by the 8x8-pixel tile of the value map their
+ * corners land in (count / scan / fill: exact list sizes), then one workgroup per (n, head, tile)
+ * sums its list on the matrix cores and STORES the tile: every grad_value element is written exactly
+ * once, whatever it held on entry.  grad_loc / grad_attn (d_offsets / d_logits) come from the gather
+ * kernels above with their scatter switched off.
+ *   shapes_host / lsi_host : HOST copies of spatial_shapes / level_start_index (the grid and the
+ *                            workspace are sized from them; the device copies are still passed for
+ *                            the gather kernel).  Every level must be a window of [0, S).
+ *   ws / ws_bytes          : device workspace of at least vah_msda_tile_ws_bytes(...) bytes, 16-byte
+ *                            aligned, contents arbitrary (list counters, offsets, entries)
+ *   needs D == 32, P == 4, 1 <= L <= 4 (VAH_E_UNSUPPORTED otherwise: use the functions above)
+ * vah_msda_fused_backward_tiled: grad_value_dtype 0 = fp32, 1 = bf16 (bf16 values only).
+ * ------------------------------------------------------------------------------------ */
+int64_t vah_msda_tile_ws_bytes(int64_t N, int64_t S, int64_t M, int64_t L, int64_t Lq, int64_t P,
+                               const int64_t *shapes_host, const int64_t *lsi_host);     /* < 0: not supported */
+int vah_msda_backward_tiled_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
+                                const float *loc, const float *attn, const float *grad_out, int64_t N,
+                                int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P,
+                                float *grad_value, float *grad_loc, float *grad_attn,
+                                const int64_t *shapes_host, const int64_t *lsi_host, void *ws,
+                                int64_t ws_bytes, void *stream);
+int vah_msda_fused_backward_tiled(const void *value, int value_dtype, const int64_t *shapes,
+                                  const int64_t *lsi, const void *offsets, const void *logits,
+                                  int param_dtype, const float *ref, int64_t ref_levels,
+                                  const void *grad_out, int64_t N, int64_t S, int64_t M, int64_t D,
+                                  int64_t L, int64_t Lq, int64_t P, void *grad_value,
+                                  int grad_value_dtype, void *d_offsets, void *d_logits,
+                                  const int64_t *shapes_host, const int64_t *lsi_host, void *ws,
+                                  int64_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
  * Softmax attention of the ViT blocks, bf16, head_dim 64  
  *
  * Replaces the score / softmax / value products of the reference's Attention and

@@ -22,6 +22,7 @@
 //   * spatial_shapes / level_start_index stay on the device (scalar loads), as in the
 //     reference: no host sync anywhere.
 #include "msda_common.h"
+#include "msda_internal.h"
 
 #include <cstdlib>
 
@@ -152,7 +153,7 @@ __device__ __forceinline__ float group_sum(float x) {
 template <int D>
 constexpr int kResultLane = (D == 32) ? 16 : 0;
 
-template <int D, int PU>
+template <int D, int PU, bool SCATTER = true>
 __global__ __launch_bounds__(kBlock) void msda_bwd_lanec(
     const float *__restrict__ value, const int64_t *__restrict__ shapes,
     const int64_t *__restrict__ lsi, const float *__restrict__ loc,
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_lanec(
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     vv[k] = t[u].ok[k] ? v[u][k] : 0.f;
-                    if (t[u].ok[k]) atomicAdd(gvl + (int64_t)t[u].row[k] * stride, t[u].cw[k] * tv);
+                    if (SCATTER && t[u].ok[k]) atomicAdd(gvl + (int64_t)t[u].row[k] * stride, t[u].cw[k] * tv);
                 }
                 const float gh = t[u].hw * (vv[2] - vv[0]) + t[u].lw * (vv[3] - vv[1]);
                 const float gw = t[u].hh * (vv[1] - vv[0]) + t[u].lh * (vv[3] - vv[2]);
@@ -224,6 +225,119 @@ __global__ __launch_bounds__(kBlock) void msda_bwd_lanec(
                     *reinterpret_cast<float2 *>(glp + 2 * s) = make_float2(pw, ph);
                     gap[s] = pa;
                 }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// d(loc), d(attn) only (no grad_value scatter: that is the tile pass of msda_tile.hip), f32, D = 32:
+// 8 lanes x float4 per row as in the forward - 16-byte corner loads, the taps of the workgroup's rows
+// computed once by one thread each and handed over through LDS, the three per-sample sums reduced
+// over the 8 lanes of a row with DPP adds.  (msda_bwd_lanec with its scatter compiled out does the
+// same with one channel per lane and 4-byte loads: 204 us on the extractor call of BASELINE
+// configs[2], against 69 us for the forward's gather of the same rows.)
+// Spec: cuh:301-403 minus ms_deform_attn_col2im_bilinear's atomics; grad_loc = (W, H) * (...), cuh:157-158.
+// ---------------------------------------------------------------------------------------
+struct TapG {           // 32 bytes: token index of each corner inside its level (-1 invalid), fractions, weight
+    int row[4];
+    float lh, lw, a;
+    int level;
+};
+
+__device__ __forceinline__ float sum8_dpp(float x) {
+    x += dpp_mov<0xB1, 0xF>(x);     // quad_perm [1,0,3,2]
+    x += dpp_mov<0x4E, 0xF>(x);     // quad_perm [2,3,0,1]
+    x += dpp_mov<0x141, 0xF>(x);    // row_half_mirror: lanes 0-7 <-> 7-0 within each 8
+    return x;                       // every lane of the 8-lane group holds the sum
+}
+
+template <int PU>
+__global__ __launch_bounds__(kBlock) void msda_bwd_taps_vec4(
+    const float *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
+    const float *__restrict__ loc, const float *__restrict__ attn, const float *__restrict__ grad_out,
+    int64_t S, int M, int L, int64_t Lq, int P, int64_t total_rows, int64_t nblocks,
+    float *__restrict__ grad_loc, float *__restrict__ grad_attn) {
+    constexpr int ROWS = kBlock / 8;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    TapG *s_tap = reinterpret_cast<TapG *>(s_raw);
+    const int64_t blk = xcd_chunked_block(nblocks);
+    if (blk >= nblocks) return;
+    const int LP = L * P;
+    auto row_of = [&](int64_t work, int &m, int64_t &n) -> int64_t {      // query-major work order (see the forward)
+        const int64_t q = work % Lq;
+        m = (int)((work / Lq) % M);
+        n = work / Lq / M;
+        return (n * Lq + q) * M + m;
+    };
+    for (int i = threadIdx.x; i < ROWS * LP; i += kBlock) {
+        const int rl = i / LP, sidx = i - rl * LP, l = sidx / P;
+        const int64_t work = blk * ROWS + rl;
+        TapG tl;
+        tl.row[0] = tl.row[1] = tl.row[2] = tl.row[3] = -1;
+        tl.lh = tl.lw = tl.a = 0.f;
+        tl.level = l;
+        const Level lv = read_level(shapes, lsi, l, S);
+        if (work < total_rows && lv.valid) {
+            int m;
+            int64_t n;
+            const int64_t row = row_of(work, m, n);
+            const float2 xy = *reinterpret_cast<const float2 *>(loc + (row * LP + sidx) * 2);
+            const Tap<float> t = make_tap<float>(xy.x, xy.y, lv.H, lv.W);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) tl.row[k] = t.ok[k] ? t.row[k] : -1;
+            tl.lh = t.lh;
+            tl.lw = t.lw;
+            tl.a = attn[row * LP + sidx];
+        }
+        s_tap[i] = tl;
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int64_t work = blk * ROWS + rl;
+    if (work >= total_rows) return;          // whole 8-lane groups leave together (after the barrier)
+    int m;
+    int64_t n;
+    const int64_t row = row_of(work, m, n);
+    const int64_t stride = (int64_t)M * 32;
+    const float *vhead = value + n * S * stride + m * 32 + sub * 4;
+    const float4 g = *reinterpret_cast<const float4 *>(grad_out + row * 32 + sub * 4);
+    float *glp = grad_loc + row * LP * 2;
+    float *gap = grad_attn + row * LP;
+    for (int s0 = 0; s0 < LP; s0 += PU) {
+        const TapG *tp = s_tap + rl * LP + s0;
+        float4 v[PU][4];
+        // P is a multiple of PU: the PU samples of this step belong to ONE level (scalar geometry loads)
+        const Level lvl = read_level(shapes, lsi, s0 / P, S);
+        Level lv[PU];
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            lv[u] = lvl;
+            const float *vl = vhead + (lv[u].valid ? lv[u].start : 0) * stride;
+            const int4 rw = *reinterpret_cast<const int4 *>(tp[u].row);
+            const int r4[4] = {rw.x, rw.y, rw.z, rw.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                // unconditional (clamped) load + select: a load under `if (valid)` is waited on alone
+                const float4 x = *reinterpret_cast<const float4 *>(vl + (int64_t)max(r4[k], 0) * stride);
+                const bool ok = r4[k] >= 0;
+                v[u][k] = make_float4(ok ? x.x : 0.f, ok ? x.y : 0.f, ok ? x.z : 0.f, ok ? x.w : 0.f);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < PU; ++u) {
+            const float lh = tp[u].lh, lw = tp[u].lw, hh = 1.f - lh, hw = 1.f - lw, a = tp[u].a;
+            auto dot4 = [&](const float4 &x) { return g.x * x.x + g.y * x.y + g.z * x.z + g.w * x.w; };
+            const float d0 = dot4(v[u][0]), d1 = dot4(v[u][1]), d2 = dot4(v[u][2]), d3 = dot4(v[u][3]);
+            const float val = hh * hw * d0 + hh * lw * d1 + lh * hw * d2 + lh * lw * d3;
+            const float gh = hw * (d2 - d0) + lw * (d3 - d1);
+            const float gw = hh * (d1 - d0) + lh * (d3 - d2);
+            const float pa = sum8_dpp(val);
+            const float pw = sum8_dpp((float)lv[u].W * gw * a);
+            const float ph = sum8_dpp((float)lv[u].H * gh * a);
+            if (sub == ((s0 + u) & 7)) {
+                *reinterpret_cast<float2 *>(glp + 2 * (s0 + u)) = lv[u].valid ? make_float2(pw, ph) : make_float2(0.f, 0.f);
+                gap[s0 + u] = lv[u].valid ? pa : 0.f;
             }
         }
     }
@@ -405,7 +519,7 @@ int launch_fwd_vec4(const Dims &d, const float *value, const int64_t *shapes, co
     return check_launch("msda forward launch");
 }
 
-template <int D>
+template <int D, bool SCATTER = true>
 int launch_bwd_lanec(const Dims &d, const float *value, const int64_t *shapes, const int64_t *lsi,
                      const float *loc, const float *attn, const float *gout, float *gv, float *gl,
                      float *ga, hipStream_t st) {
@@ -414,7 +528,7 @@ int launch_bwd_lanec(const Dims &d, const float *value, const int64_t *shapes, c
     const int64_t grid = (nblocks + 7) / 8 * 8;
     if (grid >= ((int64_t)1 << 31)) return fail(VAH_E_SHAPE, "msda backward: grid too large");
 #define VAH_BWD(PU)                                                                             \
-    hipLaunchKernelGGL((msda_bwd_lanec<D, PU>), dim3((unsigned)grid), dim3(kBlock), 0, st,      \
+    hipLaunchKernelGGL((msda_bwd_lanec<D, PU, SCATTER>), dim3((unsigned)grid), dim3(kBlock), 0, st, \
                        value, shapes, lsi, loc, attn, gout, d.S, (int)d.M, (int)d.L, d.Lq,      \
                        (int)d.P, d.rows, nblocks, gv, gl, ga)
     if (d.P % 4 == 0) VAH_BWD(4);
@@ -483,6 +597,29 @@ int backward_impl(const char *fn, const T *value, const int64_t *shapes, const i
 }
 
 }  // namespace
+
+int msda_grad_taps_f32(const float *value, const int64_t *shapes, const int64_t *lsi, const float *loc, const float *attn,
+                       const float *grad_out, int64_t N, int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P,
+                       float *grad_loc, float *grad_attn, hipStream_t st) {
+    Dims d;
+    if (int rc = check_dims("msda_grad_taps_f32", N, S, M, D, L, Lq, P, &d)) return rc;
+    if (D != 32) return fail(VAH_E_UNSUPPORTED, "msda_grad_taps_f32: needs D == 32");
+    const int64_t smem = (int64_t)(kBlock / 8) * L * P * (int64_t)sizeof(TapG);
+    if (P % 4 == 0 && smem <= 48 * 1024 && aligned(value, 16) && aligned(grad_out, 16) && aligned(loc, 8) &&
+        aligned(grad_loc, 8)) {
+        constexpr int ROWS = kBlock / 8;
+        const int64_t nblocks = (d.rows + ROWS - 1) / ROWS;
+        const int64_t grid = (nblocks + 7) / 8 * 8;
+        if (grid >= ((int64_t)1 << 31)) return fail(VAH_E_SHAPE, "msda_grad_taps_f32: grid too large");
+        hipLaunchKernelGGL((msda_bwd_taps_vec4<4>), dim3((unsigned)grid), dim3(kBlock), (size_t)smem, st, value, shapes, lsi, loc,
+                           attn, grad_out, d.S, (int)d.M, (int)d.L, d.Lq, (int)d.P, d.rows, nblocks, grad_loc, grad_attn);
+        return check_launch("msda_grad_taps_f32");
+    }
+    // grad_value is never touched with SCATTER off; the value pointer stands in for it
+    return launch_bwd_lanec<32, false>(d, value, shapes, lsi, loc, attn, grad_out, const_cast<float *>(value), grad_loc,
+                                       grad_attn, st);
+}
+
 }  // namespace vah
 
 extern "C" {

@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "msda_common.h"
+#include "msda_internal.h"
 
 namespace vah {
 namespace {
@@ -76,6 +77,7 @@ __device__ __forceinline__ void row_softmax(const PT *__restrict__ lg, float (&p
 }
 
 constexpr int kD = 32;
+constexpr float kNoScatter = -2.f;      // near_radius sentinel: the gather kernels scatter nothing
 
 // ---------------------------------------------------------------------------------------
 // forward: 8 lanes x 4 channels per row, query-major work order (see msda.hip)
@@ -183,6 +185,7 @@ __global__ __launch_bounds__(kBlock) void msda_fused_bwd(
     int ref_levels, const VT *__restrict__ grad_out, int64_t S, int M, int64_t Lq, int64_t total_rows,
     int64_t nblocks, float near_radius, float *__restrict__ grad_value, PT *__restrict__ d_off,
     PT *__restrict__ d_logit) {
+    // near_radius == kNoScatter: grad_value is left to the tile pass (msda_tile.hip) altogether
     constexpr int LP = L * P;
     constexpr int ROWS = kBlock / kD;
     const int64_t blk = xcd_chunked_block(nblocks);
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(kBlock) void msda_fused_bwd(
 #pragma unroll
         for (int u = 0; u < P; ++u) {
             const float2 o = load2(op + 2 * (l * P + u));
-            scatter[u] = !(fabsf(o.x) <= near_radius && fabsf(o.y) <= near_radius);
+            scatter[u] = near_radius != kNoScatter && !(fabsf(o.x) <= near_radius && fabsf(o.y) <= near_radius);
             // an invalid level gates every sample off (W = H = 0 would not): use a location that fails
             t[u] = make_tap<float>(lv.valid ? rp.x + o.x / (float)lv.W : -8.f,
                                    lv.valid ? rp.y + o.y / (float)lv.H : -8.f, max(lv.H, 1), max(lv.W, 1));
@@ -317,7 +320,7 @@ void msda_fused_bwd_vec4(
             for (int k = 0; k < 4; ++k) tl.row[k] = (lv.valid && t.ok[k]) ? t.row[k] : -1;
             tl.lh = t.lh;
             tl.lw = t.lw;
-            tl.far = (lv.valid && !(fabsf(o.x) <= near_radius && fabsf(o.y) <= near_radius)) ? 1 : 0;
+            tl.far = (lv.valid && near_radius != kNoScatter && !(fabsf(o.x) <= near_radius && fabsf(o.y) <= near_radius)) ? 1 : 0;
         }
         s_tap[i] = tl;
     }
@@ -836,6 +839,7 @@ struct FusedArgs {
     const int *tile_meta = nullptr, *cand = nullptr;    // optional pull schedule
     int64_t ntiles = 0, cap = 0;
     float near_radius = -1.f;
+    bool taps_only = false;          // d(offsets), d(logits) only: grad_value belongs to the tile pass (msda_tile.hip)
     hipStream_t st;
 };
 
@@ -858,11 +862,11 @@ int launch_bwd(const FusedArgs &a) {
     const int64_t grid = (nblocks + 7) / 8 * 8;
     if (grid >= ((int64_t)1 << 31)) return fail(VAH_E_SHAPE, "msda fused backward: grid too large");
     const bool wide = a.N * a.S * a.M * kD * (int64_t)sizeof(VT) >= ((int64_t)1 << 32);   // vec4 kernel: 32-bit offsets
-    if (!a.tile_meta || wide) {
+    if ((!a.tile_meta && !a.taps_only) || wide) {
         hipLaunchKernelGGL((msda_fused_bwd<VT, PT, L, P>), dim3((unsigned)grid), dim3(kBlock), 0, a.st,
                            (const VT *)a.value, a.shapes, a.lsi, (const PT *)a.off, (const PT *)a.logit, a.ref,
-                           a.ref_levels, (const VT *)a.grad_out, a.S, (int)a.M, a.Lq, rows, nblocks, -1.f,
-                           a.grad_value, (PT *)a.d_off, (PT *)a.d_logit);
+                           a.ref_levels, (const VT *)a.grad_out, a.S, (int)a.M, a.Lq, rows, nblocks,
+                           a.taps_only ? kNoScatter : -1.f, a.grad_value, (PT *)a.d_off, (PT *)a.d_logit);
         return check_launch("msda fused backward launch");
     }
     {
@@ -871,9 +875,10 @@ int launch_bwd(const FusedArgs &a) {
         hipLaunchKernelGGL((msda_fused_bwd_vec4<VT, PT, L, P>), dim3((unsigned)grid8), dim3(kBlock), 0, a.st,
                            (const VT *)a.value, a.shapes, a.lsi, (const PT *)a.off, (const PT *)a.logit, a.ref,
                            a.ref_levels, (const VT *)a.grad_out, a.S, (int)a.M, a.Lq, rows, nb8,
-                           a.near_radius, a.grad_value, (PT *)a.d_off, (PT *)a.d_logit);
+                           a.taps_only ? kNoScatter : a.near_radius, a.grad_value, (PT *)a.d_off, (PT *)a.d_logit);
         if (int rc = check_launch("msda fused backward (split) launch")) return rc;
     }
+    if (a.taps_only) return VAH_OK;
     // pull pass for the near samples
     const int64_t gblocks = a.N * a.M * a.ntiles;
     if (gblocks >= ((int64_t)1 << 31)) return fail(VAH_E_SHAPE, "msda fused backward: tile grid too large");
@@ -938,6 +943,21 @@ int check_common(const char *fn, int64_t N, int64_t S, int64_t M, int64_t D, int
 }
 
 }  // namespace
+
+int msda_fused_grad_taps(const void *value, int value_dtype, const int64_t *shapes, const int64_t *lsi, const void *offsets,
+                         const void *logits, int param_dtype, const float *ref, int64_t ref_levels, const void *grad_out,
+                         int64_t N, int64_t S, int64_t M, int64_t L, int64_t Lq, int64_t P, void *d_offsets, void *d_logits,
+                         hipStream_t st) {
+    FusedArgs a{};
+    a.value = value, a.off = offsets, a.logit = logits, a.shapes = shapes, a.lsi = lsi, a.ref = ref;
+    a.ref_levels = (int)ref_levels, a.N = N, a.S = S, a.M = M, a.L = L, a.Lq = Lq, a.P = P;
+    a.grad_out = grad_out, a.d_off = d_offsets, a.d_logit = d_logits;
+    a.grad_value = nullptr;          // never dereferenced: nothing scatters in this mode
+    a.taps_only = true;
+    a.st = st;
+    return dispatch<true>(a, value_dtype, param_dtype);
+}
+
 }  // namespace vah
 
 extern "C" {

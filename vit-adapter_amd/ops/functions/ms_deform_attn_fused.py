@@ -113,6 +113,11 @@ def pull_schedule_for(reference_points, spatial_shapes, dense=False):
     return hit[0]
 
 
+def tiled_backward(n_levels, n_points):
+    """The atomic-free tile pass serves P == 4, L <= 4 (VAH_MSDA_TILED=0: the round-1 pull / atomic kernels)."""
+    return n_points == 4 and 1 <= n_levels <= 4 and os.environ.get('VAH_MSDA_TILED', '1') != '0'
+
+
 class MSDeformAttnFusedFunction(Function):
     """apply(value (N,S,M,32), spatial_shapes, level_start_index, offsets (N,Lq,M,L,P,2),
     logits (N,Lq,M,L*P), reference_points (1,Lq,1|L,2)) -> (N, Lq, M*32) in value's dtype."""
@@ -132,7 +137,8 @@ class MSDeformAttnFusedFunction(Function):
                 out.data_ptr(), torch.cuda.current_stream(value.device).cuda_stream)
         _vah.check(rc, 'vah_msda_fused_forward')
         ctx.save_for_backward(value, spatial_shapes, level_start_index, offsets, logits, ref)
-        ctx.pull = pull_schedule_for(reference_points, spatial_shapes, dense_pull(value.dtype))
+        ctx.tiled = tiled_backward(L, P)
+        ctx.pull = None if ctx.tiled else pull_schedule_for(reference_points, spatial_shapes, dense_pull(value.dtype))
         return out
 
     @staticmethod
@@ -142,10 +148,26 @@ class MSDeformAttnFusedFunction(Function):
         N, S, M, D = value.shape
         _, Lq, _, L, P, _ = offsets.shape
         grad_output = grad_output.contiguous().to(value.dtype)
-        grad_value = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
         d_off = torch.empty_like(offsets)
         d_logit = torch.empty_like(logits)
-        pull = ctx.pull
+        if ctx.tiled:
+            # atomic-free tile pass (csrc/msda_tile.hip): grad_value is STORED, in the value's dtype
+            sh_host, lsi_host, _ = _vah.host_geometry(shapes, lsi)
+            ws_bytes = _vah.lib.vah_msda_tile_ws_bytes(N, S, M, L, Lq, P, sh_host, lsi_host)
+            if ws_bytes >= 0:
+                grad_value = torch.empty_like(value)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
+                with torch.cuda.device(value.device):
+                    rc = _vah.lib.vah_msda_fused_backward_tiled(
+                        value.data_ptr(), _DT[value.dtype], shapes.data_ptr(), lsi.data_ptr(),
+                        offsets.data_ptr(), logits.data_ptr(), _DT[offsets.dtype], ref.data_ptr(),
+                        ref.shape[1], grad_output.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
+                        _DT[value.dtype], d_off.data_ptr(), d_logit.data_ptr(), sh_host, lsi_host,
+                        ws.data_ptr(), ws_bytes, torch.cuda.current_stream(value.device).cuda_stream)
+                _vah.check(rc, 'vah_msda_fused_backward_tiled')
+                return grad_value, None, None, d_off, d_logit, None
+        grad_value = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
+        pull = ctx.pull if not ctx.tiled else None
         with torch.cuda.device(value.device):
             rc = _vah.lib.vah_msda_fused_backward(
                 value.data_ptr(), _DT[value.dtype], shapes.data_ptr(), lsi.data_ptr(),
