@@ -408,8 +408,8 @@ def main():
                         'traffic': pmc_traffic(dom, args, preset_kw),
                         'avg_launch_us': msda[dom]['avg_us'],
                         'algorithmic_bytes_per_launch': msda[dom]['bytes_per_launch'],
-                        'bytes_are': 'moved for the IO dtypes of the launch (%s value / offsets / logits / grad_out, '
-                                     'fp32 grad_value)' % args.dtype,
+                        'bytes_are': 'moved for the IO dtypes of the launch: value, out / grad_out, offsets, logits and their '
+                                     'gradients in %s (grad_value too: the tile pass stores it in the value dtype)' % args.dtype,
                         'frac_fp32_definition': msda[dom].get('frac_fp32_definition')}
         if args.boundary_iters > 0 and world == 1:
             kernels.update(boundary_kernels(dev, args.boundary_iters))

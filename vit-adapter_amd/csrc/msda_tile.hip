@@ -85,6 +85,25 @@ __device__ __forceinline__ int64_t list_entry_base(const TileGeom &g, int64_t n,
 struct PlainSrc {
     const float *loc, *attn;
     int LP;
+    float *grad_loc, *grad_attn;           // outputs of the tile pass (spec cuh:156-158)
+    // gradients of the P samples of (row, level): own = bit p set when this caller owns sample p
+    __device__ __forceinline__ void store_grads(int64_t row, int l, unsigned own, const float (&gx)[kP], const float (&gy)[kP],
+                                                const float (&ga)[kP], int H, int W) const {
+        float *gl = grad_loc + (row * LP + l * kP) * 2;
+        float *gt = grad_attn + row * LP + l * kP;
+        if (own == 0xFu) {
+            *reinterpret_cast<float4 *>(gl) = make_float4((float)W * gx[0], (float)H * gy[0], (float)W * gx[1], (float)H * gy[1]);
+            *reinterpret_cast<float4 *>(gl + 4) = make_float4((float)W * gx[2], (float)H * gy[2], (float)W * gx[3], (float)H * gy[3]);
+            *reinterpret_cast<float4 *>(gt) = make_float4(ga[0], ga[1], ga[2], ga[3]);
+        } else {
+#pragma unroll
+            for (int p = 0; p < kP; ++p)
+                if ((own >> p) & 1) {
+                    *reinterpret_cast<float2 *>(gl + 2 * p) = make_float2((float)W * gx[p], (float)H * gy[p]);
+                    gt[p] = ga[p];
+                }
+        }
+    }
     struct Raw {
         float4 xy[2];       // P = 4 locations
         float4 a;
@@ -123,6 +142,42 @@ struct FusedSrc {
     static constexpr int LP = L * kP;
     static constexpr int OW = kP * 2 * (int)sizeof(PT) / 4;      // words of one level's offsets (4 or 8)
     static constexpr int LW = LP * (int)sizeof(PT) / 4;          // words of the row's logits (even)
+    PT *d_off;                             // output: d(offsets) = attention x d(out)/d(pixel position) (the level size cancels)
+    float *ga;                             // scratch (N,Lq,M,L*P) fp32: d(out)/d(attention probability), for the softmax backward
+    __device__ __forceinline__ void store_grads(int64_t row, int l, unsigned own, const float (&gx)[kP], const float (&gy)[kP],
+                                                const float (&gav)[kP], int H, int W) const {
+        PT *dp = d_off + (row * LP + l * kP) * 2;
+        float *gp = ga + row * LP + l * kP;
+        if (own == 0xFu) {
+            if constexpr (sizeof(PT) == 2) {
+                bf16x8 o;
+#pragma unroll
+                for (int p = 0; p < kP; ++p) {
+                    o[2 * p] = (__bf16)gx[p];
+                    o[2 * p + 1] = (__bf16)gy[p];
+                }
+                *reinterpret_cast<bf16x8 *>(dp) = o;
+            } else {
+                *reinterpret_cast<float4 *>(dp) = make_float4(gx[0], gy[0], gx[1], gy[1]);
+                *reinterpret_cast<float4 *>(dp + 4) = make_float4(gx[2], gy[2], gx[3], gy[3]);
+            }
+            *reinterpret_cast<float4 *>(gp) = make_float4(gav[0], gav[1], gav[2], gav[3]);
+        } else {
+#pragma unroll
+            for (int p = 0; p < kP; ++p)
+                if ((own >> p) & 1) {
+                    if constexpr (sizeof(PT) == 2) {
+                        bf16x2 o;
+                        o[0] = (__bf16)gx[p];
+                        o[1] = (__bf16)gy[p];
+                        *reinterpret_cast<bf16x2 *>(dp + 2 * p) = o;
+                    } else {
+                        *reinterpret_cast<float2 *>(dp + 2 * p) = make_float2(gx[p], gy[p]);
+                    }
+                    gp[p] = gav[p];
+                }
+        }
+    }
     struct Raw {
         uint32_t o[OW];
         uint32_t lg[LW];
@@ -213,7 +268,7 @@ constexpr int kCtrStride = 32;      // ints between two list counters (one 128-b
 constexpr int kBinTable = 4096;     // tiles of one level the LDS table covers (more: direct global atomics)
 constexpr int kBinBox = 4;          // tiles of a thread's box binned through the table (more: direct)
 
-template <typename Src>
+template <typename Src, bool TAPS>
 __global__ __launch_bounds__(256) void msda_bin(Src src, TileGeom g, int M, int Lq, int *__restrict__ counter,
                                                 int *__restrict__ entries) {
     __shared__ int s_cnt[kBinTable];
@@ -230,6 +285,7 @@ __global__ __launch_bounds__(256) void msda_bin(Src src, TileGeom g, int M, int 
     if (live) {
         const int64_t row = ((int64_t)n * Lq + q) * M + m;
         const typename Src::Raw raw = src.template load<false>(row, q, l);
+        unsigned orphan = 0;
 #pragma unroll
         for (int p = 0; p < kP; ++p) {
             const float2 xy = src.xy(raw, p, H, W);
@@ -237,10 +293,17 @@ __global__ __launch_bounds__(256) void msda_bin(Src src, TileGeom g, int M, int 
             // corner rows y0, y0 + 1 clipped to the map (y0 >= -1, y0 <= H - 1 when inside)
             const int ya = max(b.y0, 0) >> kTShY, yb = min(b.y0 + 1, H - 1) >> kTShY;
             const int xa = max(b.x0, 0) >> kTShX, xb = min(b.x0 + 1, W - 1) >> kTShX;
+            orphan |= b.inside ? 0u : 1u << p;          // no corner anywhere: no tile will own this sample
             ty0 = b.inside ? min(ty0, ya) : ty0;
             ty1 = b.inside ? max(ty1, yb) : ty1;
             tx0 = b.inside ? min(tx0, xa) : tx0;
             tx1 = b.inside ? max(tx1, xb) : tx1;
+        }
+        // a sample inside the gate has its corner (max(y0,0), max(x0,0)) in the map, so some tile owns it and writes
+        // its gradients; the others (gate failed: spec cuh:288) get their zeros here
+        if (TAPS && orphan) {
+            const float z[kP] = {0.f, 0.f, 0.f, 0.f};
+            src.store_grads(row, l, orphan, z, z, z, H, W);
         }
     }
     const int bw = tx1 - tx0 + 1, bh = ty1 - ty0 + 1;
@@ -283,17 +346,47 @@ __global__ __launch_bounds__(256) void msda_bin(Src src, TileGeom g, int M, int 
 // LDS per wave: Wt[32 px + 1 dummy][WS] fp32 + G[64 entries][32 ch] in the grad_out dtype.
 //   bf16: WS = 68 (272-byte rows: the 8-float fragment reads are conflict-free ds_read_b128)
 //   fp32: WS = 65 (the one-float fragment reads of v_mfma_f32_32x32x2_f32 are conflict-free)
+constexpr int kWinW = kTW + 1, kWinH = kTH + 1;        // value window of a tile: the tile + one pixel to the right / below
+
 template <typename GT>
 struct TileLds {
     static constexpr int WS = std::is_same<GT, float>::value ? 65 : 68;
     static constexpr int w_floats = ((kTilePx + 1) * WS + 3) / 4 * 4;      // + one dummy row for the corners outside the tile
     static constexpr int g_bytes = 64 * kD * (int)sizeof(GT);
-    static constexpr int per_wave = (w_floats * 4 + g_bytes + 15) / 16 * 16;
+    static constexpr int v_bytes = kWinW * kWinH * kD * (int)sizeof(GT);   // value rows of the window (16-byte multiple)
+    static constexpr int per_wave_taps = (w_floats * 4 + g_bytes + v_bytes + 15) / 16 * 16;
+    static constexpr int per_wave_plain = (w_floats * 4 + g_bytes + 15) / 16 * 16;
 };
 
-template <typename GT, typename OT, typename Src>
+// <grad_out row, value row> over the 32 channels; g: the lane's grad_out row as loaded (raw 16-byte pieces)
+template <typename GT>
+__device__ __forceinline__ float row_dot(const uint4 (&g)[kD * sizeof(GT) / 16], const unsigned char *vrow) {
+    float d = 0.f;
+    if constexpr (sizeof(GT) == 2) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(vrow + 16 * i);
+            d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, g[i].x), __builtin_bit_cast(bf16x2, v.x), d, false);
+            d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, g[i].y), __builtin_bit_cast(bf16x2, v.y), d, false);
+            d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, g[i].z), __builtin_bit_cast(bf16x2, v.z), d, false);
+            d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, g[i].w), __builtin_bit_cast(bf16x2, v.w), d, false);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 v = *reinterpret_cast<const float4 *>(vrow + 16 * i);
+            d += __builtin_bit_cast(float, g[i].x) * v.x + __builtin_bit_cast(float, g[i].y) * v.y +
+                 __builtin_bit_cast(float, g[i].z) * v.z + __builtin_bit_cast(float, g[i].w) * v.w;
+        }
+    }
+    return d;
+}
+
+// TAPS: the tile also computes d(location) / d(attention) of the samples it owns (else a gather kernel of
+// msda.hip / msda_fused.hip does, and the value window is not loaded).
+template <typename GT, typename OT, typename Src, bool TAPS>
 __global__ __launch_bounds__(kTileThreads) void msda_tile_gv(Src src, TileGeom g, int M, int64_t Lq, int64_t S,
-                                                             const GT *__restrict__ grad_out,
+                                                             const GT *__restrict__ value, const GT *__restrict__ grad_out,
                                                              int *__restrict__ counter,
                                                              const int *__restrict__ entries, int64_t nwgs, int N,
                                                              float *__restrict__ slabs, OT *__restrict__ grad_value) {
@@ -301,9 +394,10 @@ __global__ __launch_bounds__(kTileThreads) void msda_tile_gv(Src src, TileGeom g
     constexpr int WS = LD::WS;
     constexpr bool F32 = std::is_same<GT, float>::value;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    float *Wt = reinterpret_cast<float *>(smem + (size_t)wave * LD::per_wave);
-    GT *Gs = reinterpret_cast<GT *>(smem + (size_t)wave * LD::per_wave + (size_t)LD::w_floats * 4);
+    const int lane = threadIdx.x & 63;
+    float *Wt = reinterpret_cast<float *>(smem);                 // one wave per workgroup
+    GT *Gs = reinterpret_cast<GT *>(smem + (size_t)LD::w_floats * 4);
+    unsigned char *Vs = smem + (size_t)LD::w_floats * 4 + LD::g_bytes;
 
     const int64_t wg = xcd_chunked_block(nwgs);
     if (wg >= nwgs) return;
@@ -329,6 +423,22 @@ __global__ __launch_bounds__(kTileThreads) void msda_tile_gv(Src src, TileGeom g
     // zero this wave's Wt (16-byte stores; the region is a multiple of 16 bytes)
     for (int i = lane * 4; i < LD::w_floats; i += 64 * 4)
         *reinterpret_cast<float4 *>(Wt + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+    // the value rows of this head in the tile's window (tile + 1 pixel right / below; zeros outside the map):
+    // what the samples OWNED by this tile interpolate for d(location) / d(attention)
+    constexpr int ROWB = kD * (int)sizeof(GT);
+    if (TAPS) {
+        constexpr int PCS = ROWB / 16;
+        const int64_t vstride = (int64_t)M * kD;
+        const GT *vmap = value + ((int64_t)n * S + g.start[l]) * vstride + m * kD;
+        for (int i = lane; i < kWinW * kWinH * PCS; i += 64) {
+            const int wp = i / PCS, pc = i - wp * PCS;
+            const int yy = ty * kTH + wp / kWinW, xx = tx * kTW + wp % kWinW;
+            const bool in = yy < H && xx < W;
+            const uint4 v = *reinterpret_cast<const uint4 *>(
+                reinterpret_cast<const unsigned char *>(vmap + ((int64_t)min(yy, H - 1) * W + min(xx, W - 1)) * vstride) + 16 * pc);
+            *reinterpret_cast<uint4 *>(Vs + wp * ROWB + 16 * pc) = in ? v : make_uint4(0, 0, 0, 0);
+        }
+    }
 
     f32x16 acc;
 #pragma unroll
@@ -365,6 +475,7 @@ __global__ __launch_bounds__(kTileThreads) void msda_tile_gv(Src src, TileGeom g
     };
     auto live_of = [&](int chunk) -> bool { return chunk < nchunks && chunk * 64 + lane < nent; };
     bool live = false;
+    int64_t row = 0;                                            // (n, q, m) row of this lane's entry
     typename Src::Raw raw{};
     uint4 gr[NV];
 #pragma unroll
@@ -374,7 +485,7 @@ __global__ __launch_bounds__(kTileThreads) void msda_tile_gv(Src src, TileGeom g
         const int64_t q = first_entry();
         q_n = entry_of(j + STEP);
         live = live_of(j);
-        const int64_t row = (n * Lq + q) * M + m;
+        row = (n * Lq + q) * M + m;
         raw = src.template load<true>(row, q, l);
         const uint4 *src4 = reinterpret_cast<const uint4 *>(grad_out + row * kD);
 #pragma unroll
@@ -398,13 +509,19 @@ __global__ __launch_bounds__(kTileThreads) void msda_tile_gv(Src src, TileGeom g
 #pragma unroll
             for (int i = 0; i < NV; ++i) dst4[i] = live ? gr[i] : make_uint4(0, 0, 0, 0);
         }
-        // ---- column `lane` of Wt: attention x bilinear weight of every corner that lands in this tile.
-        // The four corners of a sample are four different pixels: their read-add-writes go out together (four
-        // reads, then four writes); a corner that is outside the tile / the map / the list goes to the dummy
-        // row 64 with weight 0, so nothing here branches.
-        unsigned touched[kP];                    // 4 x 8 bits per sample: pixel row (64 = dummy)
+        // ---- per sample of the entry:
+        //  (1) column `lane` of Wt: attention x bilinear weight of every corner that lands in this tile.  The four
+        //      corners of a sample are four different pixels: their read-add-writes go out together (four reads,
+        //      then four writes); a corner that is outside the tile / the map / the list goes to the dummy row
+        //      with weight 0, so nothing here branches;
+        //  (2) if this tile OWNS the sample (its first corner inside the map, in the order 00 01 10 11, lies in the
+        //      tile - every sample that passes the gate has exactly one owner, and the owner's list holds it):
+        //      d(out)/d(location), d(out)/d(attention) from the value window (spec cuh:126-158: the four corner
+        //      dot products <grad_out, value>, each a lane-local chain - no cross-lane reduction).
+        float *wcell[kP][4];                     // the cells written, for the clean-up after the matrix phase
         {
-            float a[kP];
+            float a[kP], gx[kP], gy[kP], gav[kP];
+            unsigned own = 0;
             src.weights(raw, l, a);
 #pragma unroll
             for (int p = 0; p < kP; ++p) {
@@ -412,25 +529,43 @@ __global__ __launch_bounds__(kTileThreads) void msda_tile_gv(Src src, TileGeom g
                 const Base b = make_base(xy.x, xy.y, H, W);
                 const float hh = 1.f - b.lh, hw = 1.f - b.lw;
                 const float cw[4] = {hh * hw, hh * b.lw, b.lh * hw, b.lh * b.lw};
-                float *d[4];
+                const int ry = b.y0 - ty * kTH, rx = b.x0 - tx * kTW;
+                const bool on = live && b.inside;
+                const bool vy[2] = {on && b.y0 >= 0, on && b.y0 + 1 <= H - 1};       // corner row in the map
+                const bool vx[2] = {b.x0 >= 0, b.x0 + 1 <= W - 1};
+                const bool iy[2] = {(unsigned)ry < (unsigned)kTH, (unsigned)(ry + 1) < (unsigned)kTH};     // ... in the tile
+                const bool ix[2] = {(unsigned)rx < (unsigned)kTW, (unsigned)(rx + 1) < (unsigned)kTW};
+                bool valid[4], mine[4];
                 float wgt[4], old[4];
-                unsigned tch = 0;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const int yy = b.y0 + (c >> 1), xx = b.x0 + (c & 1);
-                    const bool ok = live && b.inside && yy >= 0 && yy <= H - 1 && xx >= 0 && xx <= W - 1 &&
-                                    (yy >> kTShY) == ty && (xx >> kTShX) == tx;
-                    const int px = ok ? (((yy & (kTH - 1)) << kTShX) | (xx & (kTW - 1))) : kTilePx;
-                    d[c] = Wt + px * WS + lane;
-                    wgt[c] = ok ? a[p] * cw[c] : 0.f;
-                    tch |= (unsigned)px << (8 * c);
+                    valid[c] = vy[c >> 1] && vx[c & 1];
+                    mine[c] = valid[c] && iy[c >> 1] && ix[c & 1];
+                    const int px = mine[c] ? (ry + (c >> 1)) * kTW + rx + (c & 1) : kTilePx;
+                    wcell[p][c] = Wt + px * WS + lane;
+                    wgt[c] = mine[c] ? a[p] * cw[c] : 0.f;
                 }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) old[c] = *d[c];
+                for (int c = 0; c < 4; ++c) old[c] = *wcell[p][c];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) *d[c] = old[c] + wgt[c];
-                touched[p] = tch;
+                for (int c = 0; c < 4; ++c) *wcell[p][c] = old[c] + wgt[c];
+                const bool owned = valid[0] ? mine[0] : valid[1] ? mine[1] : valid[2] ? mine[2] : (valid[3] && mine[3]);
+                own |= owned ? 1u << p : 0u;
+                gx[p] = gy[p] = gav[p] = 0.f;
+                if (TAPS && __ballot(owned)) {                              // wave-uniform: some lane owns its sample p
+                    float d[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int wy = min(max(ry + (c >> 1), 0), kWinH - 1), wx = min(max(rx + (c & 1), 0), kWinW - 1);
+                        const float dc = row_dot<GT>(gr, Vs + (wy * kWinW + wx) * ROWB);
+                        d[c] = valid[c] ? dc : 0.f;
+                    }
+                    gav[p] = cw[0] * d[0] + cw[1] * d[1] + cw[2] * d[2] + cw[3] * d[3];
+                    gy[p] = (hw * (d[2] - d[0]) + b.lw * (d[3] - d[1])) * a[p];
+                    gx[p] = (hh * (d[1] - d[0]) + b.lh * (d[3] - d[2])) * a[p];
+                }
             }
+            if (TAPS && own) src.store_grads(row, l, own, gx, gy, gav, H, W);
         }
         __builtin_amdgcn_wave_barrier();
         // ---- dV[32 px, 32 ch] += Wt[32 px, 64 k] x G[64 k, 32 ch]
@@ -478,9 +613,9 @@ __global__ __launch_bounds__(kTileThreads) void msda_tile_gv(Src src, TileGeom g
 #pragma unroll
         for (int p = 0; p < kP; ++p)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) Wt[((touched[p] >> (8 * c)) & 0xFFu) * WS + lane] = 0.f;
+            for (int c = 0; c < 4; ++c) *wcell[p][c] = 0.f;
         __builtin_amdgcn_wave_barrier();
-        live = live_n, raw = raw_n, q_n = q_nn;
+        live = live_n, raw = raw_n, q_n = q_nn, row = row_n;
 #pragma unroll
         for (int i = 0; i < NV; ++i) gr[i] = gr_n[i];
     }
@@ -556,12 +691,50 @@ __global__ __launch_bounds__(kTileThreads) void msda_tile_gv(Src src, TileGeom g
     }
 }
 
+// ---- fused core only: softmax backward of the attention logits --------------------------------------
+// d_logit[s] = p_s * (ga_s - sum_t p_t ga_t), p = softmax(logits of the (n, q, m) row), ga = d(out)/d(p) as the
+// tile pass (and, for gated samples, the binning pass) left it in the workspace.  One thread per row.
+template <typename PT, int L>
+__global__ __launch_bounds__(256) void msda_logit_grad(const PT *__restrict__ logit, const float *__restrict__ ga, int64_t rows,
+                                                       PT *__restrict__ d_logit) {
+    constexpr int LP = L * kP;
+    const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (row >= rows) return;
+    float p[LP], g[LP];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < LP; ++s) {
+        p[s] = (float)logit[row * LP + s];
+        mx = fmaxf(mx, p[s]);
+    }
+#pragma unroll
+    for (int s = 0; s < LP; s += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(ga + row * LP + s);
+        g[s] = v.x, g[s + 1] = v.y, g[s + 2] = v.z, g[s + 3] = v.w;
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int s = 0; s < LP; ++s) {
+        p[s] = __expf(p[s] - mx);
+        sum += p[s];
+    }
+    const float inv = 1.f / sum;
+    float dot = 0.f;
+#pragma unroll
+    for (int s = 0; s < LP; ++s) {
+        p[s] *= inv;
+        dot += p[s] * g[s];
+    }
+#pragma unroll
+    for (int s = 0; s < LP; ++s) d_logit[row * LP + s] = (PT)(p[s] * (g[s] - dot));
+}
+
 // ---- host side -----------------------------------------------------------------------------------
 struct Plan {
     TileGeom g;
     int64_t nlists;                          // N * T * M
     int64_t nwgs;                            // workgroups of the tile pass
-    int64_t off_counts, off_entries, off_slabs, total;      // byte offsets in the workspace
+    int64_t off_counts, off_entries, off_slabs, off_ga, total;      // byte offsets in the workspace
 };
 
 constexpr int kChunksPerWg = 8;              // a list longer than this many 64-entry chunks (by capacity) is shared
@@ -637,40 +810,60 @@ int make_plan(const char *fn, int64_t N, int64_t S, int64_t M, int64_t L, int64_
     pl->off_counts = 0;
     pl->off_entries = up(nlists * kCtrStride * 4);
     pl->off_slabs = pl->off_entries + up(N * M * ET * 4);
-    pl->total = pl->off_slabs + up(nslabs * kTilePx * kD * 4);
+    pl->off_ga = pl->off_slabs + up(nslabs * kTilePx * kD * 4);
+    pl->total = pl->off_ga + up(N * Lq * M * L * kP * 4);           // fused core: d(out)/d(attention probability), fp32
     return VAH_OK;
 }
 
-template <typename GT, typename OT, typename Src>
-int run_tiled(const char *fn, const Src &src, const Plan &pl, int64_t N, int64_t M, int64_t Lq, int64_t S, const GT *grad_out,
-              OT *grad_value, void *ws, hipStream_t st) {
+template <typename GT, typename OT, typename Src, bool TAPS>
+int run_tiled(const char *fn, const Src &src, const Plan &pl, int64_t N, int64_t M, int64_t Lq, int64_t S, const GT *value,
+              const GT *grad_out, OT *grad_value, void *ws, hipStream_t st) {
     char *base = (char *)ws;
     int *counts = (int *)(base + pl.off_counts), *entries = (int *)(base + pl.off_entries);
     if (hipMemsetAsync(counts, 0, (size_t)pl.nlists * kCtrStride * 4, st) != hipSuccess)
         return fail(VAH_E_SHAPE, "%s: memset failed", fn);
     const dim3 bgrid((unsigned)((Lq + 255) / 256), (unsigned)(N * M * pl.g.L));
-    hipLaunchKernelGGL((msda_bin<Src>), bgrid, dim3(256), 0, st, src, pl.g, (int)M, (int)Lq, counts, entries);
+    hipLaunchKernelGGL((msda_bin<Src, TAPS>), bgrid, dim3(256), 0, st, src, pl.g, (int)M, (int)Lq, counts, entries);
     if (int rc = check_launch(fn)) return rc;
-    const int smem = TileLds<GT>::per_wave * (kTileThreads / 64);
-    if (int rc = allow_dynamic_lds((const void *)msda_tile_gv<GT, OT, Src>, smem, fn)) return rc;
+    const int smem = TAPS ? TileLds<GT>::per_wave_taps : TileLds<GT>::per_wave_plain;
+    if (int rc = allow_dynamic_lds((const void *)msda_tile_gv<GT, OT, Src, TAPS>, smem, fn)) return rc;
     const int64_t grid = (pl.nwgs + 7) / 8 * 8;
-    hipLaunchKernelGGL((msda_tile_gv<GT, OT, Src>), dim3((unsigned)grid), dim3(kTileThreads), smem, st, src, pl.g, (int)M, Lq, S,
-                       grad_out, counts, (const int *)entries, pl.nwgs, (int)N, (float *)(base + pl.off_slabs), grad_value);
+    hipLaunchKernelGGL((msda_tile_gv<GT, OT, Src, TAPS>), dim3((unsigned)grid), dim3(kTileThreads), smem, st, src, pl.g, (int)M, Lq, S,
+                       value, grad_out, counts, (const int *)entries, pl.nwgs, (int)N, (float *)(base + pl.off_slabs), grad_value);
     return check_launch(fn);
 }
 
+// Who computes d(offsets) / d(logits)?  Measured on BASELINE configs[2] (bf16, profiles/r02_msda_tile_steps.txt):
+// one level of many-entry lists (extractor: 64x64 map, ~240 entries per tile): inside the tile pass 108 us per call
+// against 127 us with the gather kernel of msda_fused.hip in front; three levels of short lists (injector):
+// 172 us against 160 us.  fp32 values (32 FMAs per corner instead of 16 packed dot products, 250 registers):
+// always the gather kernel.
+template <typename VT, int L>
+constexpr bool kTapsInTile = std::is_same<VT, __bf16>::value && L == 1;
+
 template <typename VT, typename PT, int L>
-int fused_tiled(const char *fn, const Plan &pl, const void *off, const void *logit, const float *ref, int ref_levels,
-                int64_t N, int64_t M, int64_t Lq, int64_t S, const void *grad_out, void *grad_value, int gv_bf16, void *ws,
-                hipStream_t st) {
-    FusedSrc<PT, L> src{(const PT *)off, (const PT *)logit, ref, ref_levels};
+int fused_tiled(const char *fn, const Plan &pl, const void *value, const void *off, const void *logit, const float *ref,
+                int ref_levels, int64_t N, int64_t M, int64_t Lq, int64_t S, const void *grad_out, void *grad_value, int gv_bf16,
+                void *d_off, void *d_logit, void *ws, hipStream_t st) {
+    constexpr bool TAPS = kTapsInTile<VT, L>;
+    float *ga = (float *)((char *)ws + pl.off_ga);
+    FusedSrc<PT, L> src{(const PT *)off, (const PT *)logit, ref, ref_levels, (PT *)d_off, ga};
+    int rc;
     if (gv_bf16) {
         if constexpr (std::is_same<VT, __bf16>::value)
-            return run_tiled<VT, __bf16>(fn, src, pl, N, M, Lq, S, (const VT *)grad_out, (__bf16 *)grad_value, ws, st);
+            rc = run_tiled<VT, __bf16, FusedSrc<PT, L>, TAPS>(fn, src, pl, N, M, Lq, S, (const VT *)value, (const VT *)grad_out,
+                                                            (__bf16 *)grad_value, ws, st);
         else
             return fail(VAH_E_UNSUPPORTED, "%s: a bf16 grad_value needs bf16 values", fn);
+    } else {
+        rc = run_tiled<VT, float, FusedSrc<PT, L>, TAPS>(fn, src, pl, N, M, Lq, S, (const VT *)value, (const VT *)grad_out,
+                                                       (float *)grad_value, ws, st);
     }
-    return run_tiled<VT, float>(fn, src, pl, N, M, Lq, S, (const VT *)grad_out, (float *)grad_value, ws, st);
+    if (rc || !TAPS) return rc;
+    const int64_t rows = N * Lq * M;
+    hipLaunchKernelGGL((msda_logit_grad<PT, L>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (const PT *)logit,
+                       (const float *)ga, rows, (PT *)d_logit);
+    return check_launch(fn);
 }
 
 }  // namespace
@@ -707,11 +900,11 @@ int vah_msda_backward_tiled_f32(const float *value, const int64_t *shapes, const
     hipStream_t st = (hipStream_t)stream;
     // SURVEY.md 8d bytes of the fp32 backward
     LaunchScope scope("msda_bwd_f32", 4 * (2 * N * S * M * D + 6 * N * Lq * M * L * P + N * Lq * M * D), st);
-    // d(loc), d(attn): the gather kernel of msda.hip with its scatter switched off
+    // d(loc), d(attn): the 8-lane gather kernel of msda.hip (fp32: cheaper than inside the tile pass, see kTapsInTile)
     if (int rc = msda_grad_taps_f32(value, shapes, lsi, loc, attn, grad_out, N, S, M, D, L, Lq, P, grad_loc, grad_attn, st))
         return rc;
-    PlainSrc src{loc, attn, (int)(L * P)};
-    return run_tiled<float, float>(fn, src, pl, N, M, Lq, S, grad_out, grad_value, ws, st);
+    PlainSrc src{loc, attn, (int)(L * P), grad_loc, grad_attn};
+    return run_tiled<float, float, PlainSrc, false>(fn, src, pl, N, M, Lq, S, value, grad_out, grad_value, ws, st);
 }
 
 int vah_msda_fused_backward_tiled(const void *value, int value_dtype, const int64_t *shapes, const int64_t *lsi,
@@ -739,14 +932,16 @@ int vah_msda_fused_backward_tiled(const void *value, int value_dtype, const int6
     const int64_t vs = value_dtype ? 2 : 4, ps = param_dtype ? 2 : 4, gs = grad_value_dtype ? 2 : 4;
     LaunchScope scope("msda_fused_bwd", vs * (N * S * M * D + N * Lq * M * D) + gs * N * S * M * D + ps * 6 * N * Lq * M * L * P, st,
                       4 * (2 * N * S * M * D + 6 * N * Lq * M * L * P + N * Lq * M * D));
-    // d(offsets), d(logits): the gather kernel of msda_fused.hip, nothing scattered
-    if (int rc = msda_fused_grad_taps(value, value_dtype, shapes, lsi, offsets, logits, param_dtype, ref, ref_levels, grad_out,
-                                      N, S, M, L, Lq, P, d_offsets, d_logits, st))
-        return rc;
+    // d(offsets), d(logits) from the gather kernel of msda_fused.hip (nothing scattered) where the tile pass does not
+    // compute them itself
+    if (!(value_dtype == 1 && L == 1))
+        if (int rc = msda_fused_grad_taps(value, value_dtype, shapes, lsi, offsets, logits, param_dtype, ref, ref_levels, grad_out,
+                                          N, S, M, L, Lq, P, d_offsets, d_logits, st))
+            return rc;
 #define VAH_CASE(VT, VC, PT, PC, LL)                                                                                     \
     if (value_dtype == VC && param_dtype == PC && L == LL)                                                               \
-        return fused_tiled<VT, PT, LL>(fn, pl, offsets, logits, ref, (int)ref_levels, N, M, Lq, S, grad_out, grad_value, \
-                                       grad_value_dtype, ws, st)
+        return fused_tiled<VT, PT, LL>(fn, pl, value, offsets, logits, ref, (int)ref_levels, N, M, Lq, S, grad_out,      \
+                                       grad_value, grad_value_dtype, d_offsets, d_logits, ws, st)
 #define VAH_CASES(LL)                       \
     VAH_CASE(float, 0, float, 0, LL);       \
     VAH_CASE(__bf16, 1, __bf16, 1, LL);     \
