@@ -173,5 +173,8 @@ def bench_inputs(cfg, device='cpu', seed=0):
         'cfg4_ext': (2, 16, 32, 4, 8400, [(40, 40)], [(80, 80), (40, 40), (20, 20)]),
         'cfg5_inj': (1, 16, 32, 4, 4200, [(100, 168), (50, 84), (25, 42)], [(50, 84)]),
         'cfg5_ext': (1, 16, 32, 4, 22050, [(50, 84)], [(100, 168), (50, 84), (25, 42)]),
+        # Mask2Former pixel decoder (seg/configs/_base_/models/mask2former_beit.py:41-51: 8 heads x 32, 3 levels,
+        # Lq = S): every token of the three maps queries all three maps; batch 2 = per-batch reference points
+        'cfg5_pixdec': (2, 8, 32, 4, 22050, [(100, 168), (50, 84), (25, 42)], [(100, 168), (50, 84), (25, 42)]),
     }
     return table[cfg]

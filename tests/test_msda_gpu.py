@@ -212,7 +212,7 @@ def _full_inputs(cfg, mode, seed=0):
 
 
 @pytest.mark.parametrize('cfg', ['cfg1', 'cfg2_inj', 'cfg2_ext', 'cfg3_inj', 'cfg3_ext',
-                                 'cfg4_inj', 'cfg4_ext', 'cfg5_inj', 'cfg5_ext'])
+                                 'cfg4_inj', 'cfg4_ext', 'cfg5_inj', 'cfg5_ext', 'cfg5_pixdec'])
 @pytest.mark.parametrize('mode', ['uniform', 'adapter'])
 def test_full_size_properties(MSDA, cfg, mode):
     v, s, i, l, a, g = _full_inputs(cfg, mode)
@@ -247,6 +247,34 @@ def test_full_size_properties(MSDA, cfg, mode):
     gv_b, gl_b, ga_b = MSDA.ms_deform_attn_backward(v, s, i, l, a, g, 64)
     assert torch.equal(out, out_b) and torch.equal(gl, gl_b) and torch.equal(ga, ga_b)
     assert (gv - gv_b).abs().max().item() <= 1e-3
+
+
+def test_pixel_decoder_full_size_vs_oracle(MSDA):
+    """BASELINE configs[4] call shape (Mask2Former pixel decoder: Lq = S = 22050, 8 heads, 3 levels, batch 2 -
+    /root/reference/segmentation/mmseg_custom/models/plugins/msdeformattn_pixel_decoder.py:224-242) through the
+    plain fp32 ms_deform_attn_forward / _backward (the tile-pass backward: no reference grid needed) against the C
+    oracle at the SAME size in fp64: every element of out, grad_value, grad_loc, grad_attn."""
+    v, s, i, l, a, g = _full_inputs('cfg5_pixdec', 'adapter')
+    out = MSDA.ms_deform_attn_forward(v, s, i, l, a, 64)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v, s, i, l, a, g, 64)
+    args = [v.double().cpu().numpy(), s.cpu().numpy(), i.cpu().numpy(), l.double().cpu().numpy(), a.double().cpu().numpy()]
+    ref_out = oracle_msda.forward(*args)
+    ref_gv, ref_gl, ref_ga = oracle_msda.backward(*args, g.double().cpu().numpy())
+    mask = _gate_mask_np(l.double().cpu().numpy(), s.cpu().numpy())
+    for nm, got, want in (('out', out, ref_out), ('grad_value', gv, ref_gv), ('grad_attn', ga, ref_ga)):
+        err = np.abs(got.double().cpu().numpy() - want).max()
+        assert err <= 1e-4 * max(1.0, np.abs(want).max()), (nm, err)
+    err = np.abs(np.where(mask, gl.double().cpu().numpy() - ref_gl, 0.0)).max()
+    assert err <= 1e-4 * max(1.0, np.abs(ref_gl).max()), ('grad_loc', err)
+
+
+def _gate_mask_np(loc, shapes):
+    """False where a pixel coordinate sits within 1e-4 of an integer: d(out)/d(loc) jumps there (bilinear kink) and
+    the fp32 kernel / fp64 oracle may fall on different sides."""
+    wh = shapes[:, ::-1].astype(np.float64)
+    px = loc * wh[None, None, None, :, None, :] - 0.5
+    ok = (np.abs(px - np.round(px)) > 1e-4).all(-1, keepdims=True)
+    return np.broadcast_to(ok, loc.shape)
 
 
 def test_full_size_spot_check_vs_oracle(MSDA):

@@ -32,7 +32,7 @@ def timeit(fn, iters=20, warm=3):
 
 def main():
     cfgs = sys.argv[1:] or ['cfg1', 'cfg2_inj', 'cfg2_ext', 'cfg3_inj', 'cfg3_ext', 'cfg4_inj',
-                            'cfg4_ext', 'cfg5_inj', 'cfg5_ext']
+                            'cfg4_ext', 'cfg5_inj', 'cfg5_ext', 'cfg5_pixdec']
     for cfg in cfgs:
         N, M, D, P, Lq, shapes, _ = cases.bench_inputs(cfg)
         L, S = len(shapes), sum(h * w for h, w in shapes)
