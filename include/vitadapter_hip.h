@@ -91,42 +91,6 @@ int vah_msda_backward_f64(const double *value, const int64_t *shapes, const int6
                           double *grad_value, double *grad_loc, double *grad_attn, void *stream);
 
 /* ------------------------------------------------------------------------------------
- * Windowed variants (fp32, D == 32, L <= 4): same tensors, same results up to fp32 summation
- * order, plus a QUERY SCHEDULE that lets one workgroup keep the value rows (and in the backward
- * the grad_value rows) of a spatially compact group of queries in LDS.
- *
- *   perm       (Lq,)          int32  a permutation of [0, Lq): the queries, group by group
- *   group_off  (n_groups+1,)  int32  group g owns perm[group_off[g] .. group_off[g+1])
- *   max_group                        size of the largest group (its sampling locations and
- *                                    weights, 12 bytes per sample, are kept in LDS too)
- *   budget_px                        LDS window capacity in 128-byte pixel rows; forward uses
- *                                    budget_px*128 B of LDS per workgroup; backward the same for
- *                                    its grad_value windows and, when stage != 0, as much
- *                                    again for value windows (total must stay below 160 KiB;
- *                                    with stage == 0 value corners are read from global)
- * The schedule is a performance hint only: any permutation / grouping gives the same result
- * (samples that miss the LDS windows take the plain global path).  `perm` MUST be a permutation
- * (a repeated query would be accumulated twice into grad_value); out-of-range entries are
- * skipped.  The reference has no counterpart: its kernels take one thread per output scalar
- * (ms_deform_im2col_cuda.cuh:237-299) and one global atomic per sample, corner and channel
- * (:87-159).  The schedule is shared by all batch elements.
- * ------------------------------------------------------------------------------------ */
-int vah_msda_forward_win_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
-                             const float *loc, const float *attn,
-                             const int32_t *group_off, const int32_t *perm,
-                             int64_t n_groups, int64_t max_group, int64_t budget_px,
-                             int64_t N, int64_t S, int64_t M, int64_t D,
-                             int64_t L, int64_t Lq, int64_t P,
-                             float *out, void *stream);
-int vah_msda_backward_win_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
-                              const float *loc, const float *attn, const float *grad_out,
-                              const int32_t *group_off, const int32_t *perm,
-                              int64_t n_groups, int64_t max_group, int64_t budget_px, int stage,
-                              int64_t N, int64_t S, int64_t M, int64_t D,
-                              int64_t L, int64_t Lq, int64_t P,
-                              float *grad_value, float *grad_loc, float *grad_attn, void *stream);
-
-/* ------------------------------------------------------------------------------------
  * Fused MSDeformAttn core: softmax over the L*P attention logits +
  * sampling-location arithmetic + the gather in one kernel, and their gradients in one more.
  * Replaces lines 108-128 of /root/reference/detection/ops/modules/ms_deform_attn.py.
@@ -138,26 +102,9 @@ int vah_msda_backward_win_f32(const float *value, const int64_t *shapes, const i
  *             shared by the batch (the adapter's reference grids)
  *   location  = ref + offsets / (W_l, H_l)
  * Supported: D == 32 and (L, P) in {(1,4), (3,4), (4,4)}  (vah_msda_fused_supported).
- * Backward: grad_value fp32 (N,S,M,32) zero on entry (float atomics); d_offsets / d_logits in
- * param_dtype, fully written.
- *
- * Optional PULL SCHEDULE for grad_value (tile_meta != NULL): the value maps are cut into tiles of
- * at most 256 pixels; tile_meta holds 8 int32 per tile {level, y0, x0, ny, nx, cand_start,
- * cand_count, 0} and cand the concatenated candidate query lists.  Tile t's candidates MUST include
- * every query whose reference point, in pixels of the tile's level, lies within near_radius + 2 of
- * the tile rectangle (any superset is fine).  Samples whose offset is within near_radius pixels in
- * both axes are then accumulated per tile in LDS buckets and flushed with one atomic per pixel row;
- * the others are scattered with per-sample atomics as without a schedule.  cap_entries = capacity of
- * the per-workgroup record store (10 bytes each, <= 150 KiB, even, < 65536); overflow falls back to
- * atomics, as does the whole pass when N*Lq*M >= 2^24.
- * cap_entries = 0 selects the DENSE form (bf16 values only): the candidates that put a corner into the
- * tile are compacted first (their offsets and reference point only); per tile and chunk of 64 of these
- * the in-tile (attention x bilinear) weights are added into a dense (64 pixels x 64 queries) matrix in
- * LDS and multiplied with the staged grad_out rows on the matrix cores (weights as bf16 hi + lo,
- * fp32 accumulation) - no records, no sort, no per-record row gather; tiles should be 8 x 8
- * (larger ones are processed in 64-pixel slabs).  The
- * result is the same gradient (fp32 summation order and, in the dense form, ~2^-17 relative
- * rounding of the weights aside) for any valid schedule.
+ * Backward (vah_msda_fused_backward): grad_value fp32 (N,S,M,32) zero on entry (float atomics, one per
+ * sample, corner and channel as the reference); d_offsets / d_logits in param_dtype, fully written.  It is
+ * the fallback of vah_msda_fused_backward_tiled below, which is what the modules call.
  * ------------------------------------------------------------------------------------ */
 int vah_msda_fused_supported(int64_t D, int64_t L, int64_t P);
 int vah_msda_fused_forward(const void *value, int value_dtype, const int64_t *shapes, const int64_t *lsi,
@@ -169,23 +116,24 @@ int vah_msda_fused_backward(const void *value, int value_dtype, const int64_t *s
                             const void *offsets, const void *logits, int param_dtype,
                             const float *ref, int64_t ref_levels, const void *grad_out,
                             int64_t N, int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P,
-                            float *grad_value, void *d_offsets, void *d_logits,
-                            const int32_t *tile_meta, const int32_t *cand, int64_t ntiles,
-                            float near_radius, int64_t cap_entries, void *stream);
+                            float *grad_value, void *d_offsets, void *d_logits, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * TILED BACKWARD: grad_value without atomics and without a zero-fill, for ANY sampling locations
  * (csrc/msda_tile.hip; replaces the scatter of ms_deform_im2col_cuda.cuh:87-159 as called from
- * :301-403).  The samples are binned on the device by the 8x8-pixel tile of the value map their
- * corners land in (count / scan / fill: exact list sizes), then one workgroup per (n, head, tile)
- * sums its list on the matrix cores and STORES the tile: every grad_value element is written exactly
- * once, whatever it held on entry.  grad_loc / grad_attn (d_offsets / d_logits) come from the gather
- * kernels above with their scatter switched off.
- *   shapes_host / lsi_host : HOST copies of spatial_shapes / level_start_index (the grid and the
+ * :301-403).  One binning pass puts every (n, q, m, level) row into the lists of the 8x4-pixel tiles of the
+ * value map its samples touch (fixed list capacity per level; a list that overflows is replaced by a walk over
+ * all queries: slow, exact); then one single-wave workgroup per (n, head, tile) - several for the long lists of
+ * coarse levels - sums its list on the matrix cores (weights [32 px x 64 entries] x grad_out rows [64 x 32 ch];
+ * bf16 rows: v_mfma_f32_32x32x16_bf16 with the weights as bf16 hi + lo; fp32 rows: v_mfma_f32_32x32x2_f32) and
+ * STORES the tile: every grad_value element is written exactly once, whatever it held on entry.
+ * grad_loc / grad_attn (d_offsets / d_logits) come from the gather kernels (scatter switched off) or, for the
+ * single-level bf16 call, from the tile pass itself (each sample is owned by the tile of its first corner).
+ *   shapes_host / lsi_host : HOST copies of spatial_shapes / level_start_index (the grids and the
  *                            workspace are sized from them; the device copies are still passed for
  *                            the gather kernel).  Every level must be a window of [0, S).
  *   ws / ws_bytes          : device workspace of at least vah_msda_tile_ws_bytes(...) bytes, 16-byte
- *                            aligned, contents arbitrary (list counters, offsets, entries)
+ *                            aligned, contents arbitrary (list counters, entries, partial tiles, d(out)/d(p))
  *   needs D == 32, P == 4, 1 <= L <= 4 (VAH_E_UNSUPPORTED otherwise: use the functions above)
  * vah_msda_fused_backward_tiled: grad_value_dtype 0 = fp32, 1 = bf16 (bf16 values only).
  * ------------------------------------------------------------------------------------ */

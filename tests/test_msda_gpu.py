@@ -291,94 +291,3 @@ def test_full_size_spot_check_vs_oracle(MSDA):
     _assert_close(out[:, idx.cuda()].double().cpu().numpy(), ref_out, 1e-4, 'out subset')
     _assert_close(gl[:, idx.cuda()].double().cpu().numpy(), ref_gl, 1e-4, 'gl subset')
     _assert_close(ga[:, idx.cuda()].double().cpu().numpy(), ref_ga, 1e-4, 'ga subset')
-
-
-# ---------------------------------------------------------------------------------------
-# LDS-windowed kernels (query schedules): same results for ANY schedule
-# ---------------------------------------------------------------------------------------
-def _schedules(MSDA, name, kw, Lq, dev):
-    """A few very different schedules for one case."""
-    out = {}
-    shapes = kw['shapes']
-    if kw.get('query_shapes'):
-        ref = cases.reference_grid(kw['query_shapes']).to(dev)
-        os.environ['VAH_MSDA_WIN'] = '1'           # the windowed path is opt-in
-        out['tiles'] = MSDA.build_query_schedule(ref, shapes)
-        os.environ.pop('VAH_MSDA_WIN')
-        assert out['tiles'].bwd_px > 0
-    g = torch.Generator().manual_seed(7)
-    perm = torch.randperm(Lq, generator=g).to(torch.int32).to(dev)
-    # identity order in chunks of 96 queries, generous budget
-    cuts = list(range(0, Lq, 96)) + [Lq]
-    out['chunks'] = MSDA.QuerySchedule(torch.arange(Lq, dtype=torch.int32, device=dev),
-                                       torch.tensor(cuts, dtype=torch.int32, device=dev),
-                                       len(cuts) - 1, 300, 150, True)
-    # random permutation, ragged groups (incl. empty ones), tiny budget -> mostly the fallback path
-    cuts = sorted(set(list(range(0, Lq, 150)) + [Lq] + torch.randint(0, Lq + 1, (5,), generator=g).tolist()))
-    cuts = [0, 0] + cuts[1:]                                   # an empty first group
-    out['ragged_tiny'] = MSDA.QuerySchedule(perm, torch.tensor(cuts, dtype=torch.int32, device=dev),
-                                            len(cuts) - 1, 9, 7, False)
-    out['ragged_stage'] = MSDA.QuerySchedule(perm, torch.tensor(cuts, dtype=torch.int32, device=dev),
-                                             len(cuts) - 1, 300, 150, True)
-    return out
-
-
-_WIN_CASES = sorted(k for k, v in cases.PARITY_CASES.items() if v['D'] == 32 and len(v['shapes']) <= 4)
-
-
-@pytest.mark.parametrize('name', _WIN_CASES)
-def test_windowed_kernels_match_oracle_for_any_schedule(MSDA, name):
-    kw = cases.PARITY_CASES[name]
-    value, hw, lsi, loc, attn, gout = cases.msda_inputs(name, **kw)
-    v, s, i, l, a, g = _dev((value, hw, lsi, loc, attn, gout))
-    args = [value.double().numpy(), hw.numpy(), lsi.numpy(), loc.double().numpy(), attn.double().numpy()]
-    ref = [oracle_msda.forward(*args)] + list(oracle_msda.backward(*args, gout.double().numpy()))
-    for sname, sched in _schedules(MSDA, name, kw, kw['Lq'], v.device).items():
-        out = MSDA.ms_deform_attn_forward(v, s, i, l, a, 64, schedule=sched)
-        gv, gl, ga = MSDA.ms_deform_attn_backward(v, s, i, l, a, g, 64, schedule=sched)
-        torch.cuda.synchronize()
-        for nm, x, r in zip(('out', 'gv', 'gl', 'ga'), (out, gv, gl, ga), ref):
-            _assert_close(x.double().cpu().numpy(), r, 1e-4, '%s/%s:%s' % (name, sname, nm))
-
-
-@pytest.mark.parametrize('cfg', ['cfg2_inj', 'cfg2_ext', 'cfg3_inj', 'cfg3_ext', 'cfg5_inj', 'cfg5_ext'])
-@pytest.mark.parametrize('mode', ['uniform', 'adapter'])
-def test_windowed_full_size_equals_plain(MSDA, cfg, mode):
-    """BASELINE call shapes: the tile schedule built from the adapter's reference grid gives the
-    plain kernels' results (fp32 summation order aside) and keeps the adjoint identities."""
-    v, s, i, l, a, g = _full_inputs(cfg, mode)
-    N, M, D, P, Lq, shapes, qshapes = cases.bench_inputs(cfg)
-    os.environ['VAH_MSDA_WIN'] = '1'
-    sched = MSDA.build_query_schedule(cases.reference_grid(qshapes).cuda(), shapes)
-    os.environ.pop('VAH_MSDA_WIN')
-    assert sched.bwd_px > 0
-    assert sched.Lq == Lq and int(sched.group_off[-1]) == Lq
-    assert torch.equal(torch.sort(sched.perm.long())[0], torch.arange(Lq, device='cuda'))
-    out0 = MSDA.ms_deform_attn_forward(v, s, i, l, a, 64)
-    gv0, gl0, ga0 = MSDA.ms_deform_attn_backward(v, s, i, l, a, g, 64)
-    out1 = MSDA.ms_deform_attn_forward(v, s, i, l, a, 64, schedule=sched)
-    gv1, gl1, ga1 = MSDA.ms_deform_attn_backward(v, s, i, l, a, g, 64, schedule=sched)
-    for nm, x0, x1 in (('out', out0, out1), ('gv', gv0, gv1), ('gl', gl0, gl1), ('ga', ga0, ga1)):
-        tol = 1e-4 * max(1.0, float(x0.abs().max()))
-        assert float((x0 - x1).abs().max()) <= tol, (nm, float((x0 - x1).abs().max()), tol)
-    lhs = (out1.double() * g.double()).sum().item()
-    assert abs(lhs - (v.double() * gv1.double()).sum().item()) <= 1e-5 * max(1.0, abs(lhs))
-    assert abs(lhs - (a.double() * ga1.double()).sum().item()) <= 1e-5 * max(1.0, abs(lhs))
-
-
-def test_function_uses_schedule_from_context(MSDA, Function):
-    kw = cases.PARITY_CASES['ext256_b']
-    value, hw, lsi, loc, attn, gout = cases.msda_inputs('ext256_b', **kw)
-    v, s, i, l, a, g = _dev((value, hw, lsi, loc, attn, gout))
-    os.environ['VAH_MSDA_WIN'] = '1'
-    sched = MSDA.build_query_schedule(cases.reference_grid(kw['query_shapes']).cuda(), kw['shapes'])
-    os.environ.pop('VAH_MSDA_WIN')
-    v1 = v.clone().requires_grad_(True)
-    with MSDA.query_schedule(sched):
-        out = Function.apply(v1, s, i, l, a, 64)
-    assert MSDA.current_schedule() is None
-    out.backward(g)                      # backward runs outside the context, schedule kept in ctx
-    v2 = v.clone().requires_grad_(True)
-    out2 = Function.apply(v2, s, i, l, a, 64)
-    out2.backward(g)
-    assert float((out - out2).abs().max()) <= 1e-5 and float((v1.grad - v2.grad).abs().max()) <= 1e-4

@@ -38,31 +38,11 @@ def main():
         L, S = len(shapes), sum(h * w for h, w in shapes)
         fb = 4 * (N * S * M * D + 3 * N * Lq * M * L * P + N * Lq * M * D)
         bb = 4 * (2 * N * S * M * D + 6 * N * Lq * M * L * P + N * Lq * M * D)
-        qshapes = cases.bench_inputs(cfg)[6]
         for mode in (os.environ.get('MODES', 'uniform,adapter').split(',')):
             v, s, i, l, a, g = _full_inputs(cfg, mode)
             tf = timeit(lambda: MSDA.ms_deform_attn_forward(v, s, i, l, a, 64))
             tb = timeit(lambda: MSDA.ms_deform_attn_backward(v, s, i, l, a, g, 64))
-            if os.environ.get('SWEEP'):
-                for tile in (4, 8, 16, 32):
-                    os.environ['VAH_MSDA_TILE'] = str(tile)
-                    sc = MSDA.build_query_schedule(cases.reference_grid(qshapes).cuda(), shapes)
-                    for fpx in (150, 300, 600, 1000):
-                        sc.fwd_px = fpx
-                        try:
-                            t = timeit(lambda: MSDA.ms_deform_attn_forward(v, s, i, l, a, 64, schedule=sc))
-                        except RuntimeError:
-                            continue
-                        print('   win fwd tile %2d px %4d groups %4d: %8.1f us (%.3f)' % (tile, fpx, sc.n_groups, t * 1e6, fb / t / 8e12), flush=True)
-                    for bpx, stage in ((150, True), (300, True), (500, True), (300, False), (600, False), (1000, False)):
-                        sc.bwd_px, sc.bwd_stage = bpx, stage
-                        try:
-                            t = timeit(lambda: MSDA.ms_deform_attn_backward(v, s, i, l, a, g, 64, schedule=sc))
-                        except RuntimeError:
-                            continue
-                        print('   win bwd tile %2d px %4d stage %d: %8.1f us (%.3f)' % (tile, bpx, stage, t * 1e6, bb / t / 8e12), flush=True)
-                os.environ.pop('VAH_MSDA_TILE')
-            # backward time includes the zero-fill of grad_value done by the binding
+            # backward: the tile pass stores grad_value (no zero-fill)
             print('%-9s %-8s fwd %8.1f us %7.1f GB/s (%.3f of 8TB/s) | bwd %8.1f us %7.1f GB/s (%.3f)'
                   % (cfg, mode, tf * 1e6, fb / tf / 1e9, fb / tf / 8e12, tb * 1e6, bb / tb / 1e9,
                      bb / tb / 8e12), flush=True)

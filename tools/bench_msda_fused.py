@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Micro-benchmark of the fused MSDA core (forward, backward with / without the pull schedule) at
-the BASELINE call shapes, bf16 IO as under autocast.  HIP-event timed."""
+"""Micro-benchmark of the fused MSDA core (forward; backward through the tile pass and, for A/B, through
+per-sample atomics) at the BASELINE call shapes, bf16 IO as under autocast.  HIP-event timed."""
 import os
 import sys
 
@@ -12,7 +12,6 @@ import torch  # noqa: E402
 from bench_msda import timeit  # noqa: E402
 from oracle import cases  # noqa: E402
 from ops.functions import MSDeformAttnFusedFunction  # noqa: E402
-from ops.functions import ms_deform_attn_fused as mf  # noqa: E402
 
 
 def main():
@@ -29,21 +28,18 @@ def main():
         hw = torch.as_tensor(shapes, dtype=torch.long, device='cuda')
         lsi = cases.level_start_index(shapes).cuda()
         gout = torch.randn(N, Lq, M * D, device='cuda', generator=g).to(dt)
-        fb = 4 * (N * S * M * D + 3 * N * Lq * M * L * P + N * Lq * M * D)
-        bb = 4 * (2 * N * S * M * D + 6 * N * Lq * M * L * P + N * Lq * M * D)
-        for pull in ('0', '1'):
-            os.environ['VAH_MSDA_PULL'] = pull
-            mf._PULL_CACHE.clear()
+        mb_f = 2 * (N * S * M * D + N * Lq * M * D) + 2 * 3 * N * Lq * M * L * P          # bytes moved with bf16 IO
+        mb_b = 2 * (2 * N * S * M * D + N * Lq * M * D) + 2 * 6 * N * Lq * M * L * P
+        for tiled in ('1', '0'):
+            os.environ['VAH_MSDA_TILED'] = tiled
             out = MSDeformAttnFusedFunction.apply(value, hw, lsi, off, logit, ref)
             tf = timeit(lambda: MSDeformAttnFusedFunction.apply(value, hw, lsi, off, logit, ref))
 
             def bwd():
                 torch.autograd.grad(out, [value, off, logit], gout, retain_graph=True)
             tb = timeit(bwd)
-            sched = mf.pull_schedule_for(ref, hw)
-            extra = '' if sched is None else ' tiles %d cand %d' % (sched.ntiles, sched.cand.numel())
-            print('%-9s pull=%s fwd %7.1f us (%.3f) | bwd(+zero-fill,+cast) %8.1f us (%.3f)%s'
-                  % (cfg, pull, tf * 1e6, fb / tf / 8e12, tb * 1e6, bb / tb / 8e12, extra), flush=True)
+            print('%-9s tiled=%s fwd %7.1f us (%.3f of 8 TB/s on moved bytes) | bwd %8.1f us (%.3f)'
+                  % (cfg, tiled, tf * 1e6, mb_f / tf / 8e12, tb * 1e6, mb_b / tb / 8e12), flush=True)
 
 
 if __name__ == '__main__':

@@ -1,12 +1,14 @@
 #!/usr/bin/env python
-"""Summarise rocprofv3 --pmc passes of tools/prof_msda_single.py into profiles/r01_msda_pmc.json.
+"""Summarise rocprofv3 --pmc passes of tools/prof_msda_single.py into profiles/r02_msda_pmc.json.
 
 Layout expected (one directory per pass, csv output):
     <root>/<cfg>_n<noise>_<COUNTER>/**/*counter_collection.csv      COUNTER in FETCH_SIZE, WRITE_SIZE
-    python tools/pmc_msda_summary.py <root> <iters> > profiles/r01_msda_pmc.json
+    python tools/pmc_msda_summary.py <root> <iters> > profiles/r02_msda_pmc.json
 Counter unit KiB.  hbm_bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (gfx950: FETCH_SIZE reports half of
 the bytes of wide coalesced reads, MI355X_MICROARCH.md "HBM"); per call = sum over the kernels of one
-forward (msda_fused_fwd) / backward (msda_fused_bwd_vec4 + msda_fused_bwd_gv_mfma) call.
+forward (msda_fused_fwd) / backward (msda_bin + msda_tile_gv + msda_logit_grad, or msda_fused_bwd_vec4 in front
+where the tile pass leaves d(offsets) to it) call.  The JSON is stamped with the digest of the MSDA kernel
+sources (bench.py::msda_source_digest): bench.py reports it as roofline.traffic only while they are unchanged.
 """
 import csv
 import glob
@@ -32,13 +34,13 @@ def main():
             n = r['Kernel_Name']
             if 'msda_fused_fwd' in n:
                 acc[(key, 'fwd')][counter] += float(r['Counter_Value']) / iters
-            elif 'msda_fused_bwd' in n:
+            elif any(t in n for t in ('msda_fused_bwd', 'msda_tile_gv', 'msda_bin', 'msda_logit_grad')):
                 acc[(key, 'bwd')][counter] += float(r['Counter_Value']) / iters
     out = {'_note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace only) of '
-                    'tools/prof_msda_single.py <cfg> %d <noise> (fused MSDA core, bf16 IO), MI355X, kernels as committed at the '
-                    'end of round 1.  n0 = offsets of a freshly initialised model (what bench.py runs: no far samples), '
-                    'n1 = ring bias + N(0,1) px ("adapter" offsets: ~4 %% far samples, scattered with float atomics by '
-                    'msda_fused_bwd_vec4).  Counter unit KiB; per call = sum over the kernels of one forward / backward call. '
+                    'tools/prof_msda_single.py <cfg> %d <noise> (fused MSDA core, bf16 IO), MI355X, round-2 kernels (tile-pass '
+                    'backward).  n0 = offsets of a freshly initialised model (what bench.py runs), '
+                    'n1 = ring bias + N(0,1) px ("adapter" offsets).  '
+                    'Counter unit KiB; per call = sum over the kernels of one forward / backward call. '
                     'hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 correction of MI355X_MICROARCH.md).' % iters}
     for (key, d), c in sorted(acc.items()):
         f, w = c.get('FETCH_SIZE', 0.0), c.get('WRITE_SIZE', 0.0)
@@ -50,6 +52,9 @@ def main():
             k = '%s_n0_%s' % (cfg, d)
             if k in out:
                 out['%s_%s' % (cfg, d)] = out[k]
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    out['msda_source_digest'] = bench.msda_source_digest()
     print(json.dumps(out, indent=1))
 
 

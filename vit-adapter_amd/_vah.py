@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -42,11 +42,6 @@ for _sfx in ('f32', 'f64'):
     _b.argtypes = [_p] * 6 + [_i64] * 7 + [_p] * 4
     _b.restype = ctypes.c_int
 
-lib.vah_msda_forward_win_f32.argtypes = [_p] * 7 + [_i64] * 10 + [_p, _p]
-lib.vah_msda_forward_win_f32.restype = ctypes.c_int
-lib.vah_msda_backward_win_f32.argtypes = [_p] * 8 + [_i64, _i64, _i64, ctypes.c_int] + [_i64] * 7 + [_p] * 4
-lib.vah_msda_backward_win_f32.restype = ctypes.c_int
-
 lib.vah_attn_padded_len.argtypes = [_i64]
 lib.vah_attn_padded_len.restype = _i64
 lib.vah_attn_fwd_bf16.argtypes = [_p, _p, _p, _i64, _i64, _i64, _i64, _i64, ctypes.c_float, _p, _p, _i64, _p, _p]
@@ -68,8 +63,7 @@ lib.vah_msda_fused_supported.argtypes = [_i64, _i64, _i64]
 lib.vah_msda_fused_supported.restype = ctypes.c_int
 lib.vah_msda_fused_forward.argtypes = [_p, _ci, _p, _p, _p, _p, _ci, _p, _i64] + [_i64] * 7 + [_p, _p]
 lib.vah_msda_fused_forward.restype = ctypes.c_int
-lib.vah_msda_fused_backward.argtypes = ([_p, _ci, _p, _p, _p, _p, _ci, _p, _i64, _p] + [_i64] * 7 + [_p] * 3
-                                        + [_p, _p, _i64, ctypes.c_float, _i64, _p])
+lib.vah_msda_fused_backward.argtypes = [_p, _ci, _p, _p, _p, _p, _ci, _p, _i64, _p] + [_i64] * 7 + [_p] * 4
 lib.vah_msda_fused_backward.restype = ctypes.c_int
 lib.vah_msda_tile_ws_bytes.argtypes = [_i64] * 6 + [_p, _p]
 lib.vah_msda_tile_ws_bytes.restype = _i64
@@ -132,7 +126,6 @@ EXPORTS = (
     'vah_abi_version', 'vah_last_error', 'vah_prof_enable', 'vah_prof_filter', 'vah_prof_report',
     'vah_msda_forward_f32', 'vah_msda_forward_f64',
     'vah_msda_backward_f32', 'vah_msda_backward_f64',
-    'vah_msda_forward_win_f32', 'vah_msda_backward_win_f32',
     'vah_msda_fused_supported', 'vah_msda_fused_forward', 'vah_msda_fused_backward',
     'vah_msda_tile_ws_bytes', 'vah_msda_backward_tiled_f32', 'vah_msda_fused_backward_tiled',
     'vah_attn_padded_len', 'vah_attn_fwd_bf16', 'vah_attn_bwd_workspace_bytes', 'vah_attn_bwd_bf16',

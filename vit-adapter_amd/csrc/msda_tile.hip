@@ -23,10 +23,10 @@
 //     chains, 1/16 of the bf16 rate and still ~20 us for the largest call).
 //
 // Passes (all on the caller's stream, workspace from the caller, no host sync):
-//   1. bin  : one thread per (n, m, level, q): the tiles its P = 4 samples touch, as a bit mask over an 8x8
-//             window of tiles; wave-aggregated append of q to the lists (one returning atomic per distinct
-//             list a wave names).  Lists have a fixed capacity per level (4x the mean load of uniformly
-//             spread samples); a list that overflows is simply not used:
+//   1. bin  : one thread per (n, m, level, q): the tiles its P = 4 samples touch; q is appended to their lists
+//             (per-workgroup counting in LDS, one returning global atomic per list and workgroup).  Lists have
+//             a fixed capacity per level (a multiple of the load of evenly spread samples); a list that
+//             overflows is simply not used:
 //   2. tile : one single-wave workgroup per list (13 KB of LDS: 12 per CU), lists of the 12 heads of one tile
 //             adjacent (they read the same query rows: L2 hits instead of 64-byte pieces of 128-byte lines
 //             from HBM); the wave walks its list in chunks of 64 entries.  A workgroup whose list overflowed walks ALL queries of its
@@ -254,19 +254,20 @@ __device__ __forceinline__ Base make_base(float lx, float ly, int H, int W) {
 
 // ---- pass 1: binning ----------------------------------------------------------------------------
 // grid (ceil(Lq / 256), N * M * L): a workgroup is 256 neighbouring queries of one (n, m, level).
-// Per thread: the bounding box (in tiles) of its 4 samples' corners - every tile of the box gets the query
-// (a tile that receives no corner just masks everything away later; for samples that sit within a few
-// pixels of each other the box IS the set of tiles).  The workgroup counts per tile in LDS (ds_add_rtn: the
-// slow LDS atomic unit, but only ~1.3 operations per thread), reserves each touched list's range with ONE
-// global atomic per tile - all of them in flight together - and the threads then write their entries.
+// Per thread: the tiles its 4 samples touch - per sample the 1 x 1 .. 2 x 2 block of tiles its corners fall in,
+// minus what an earlier sample of the row already named (<= 16 tiles, typically 1 or 2: the samples of a row sit
+// within a few pixels of each other in the adapter; spread over the whole map - the `uniform` recipe of the
+// reference's test.py - it is 4 to 16).  The workgroup counts per tile in LDS (ds_add_rtn: the slow LDS atomic
+// unit, but only ~1.3 operations per thread), reserves each touched list's range with ONE global atomic per
+// tile - all of them in flight together - and the threads then write their entries.
 // Earlier forms of this pass (measured on the extractor call of BASELINE configs[2]):
 //   * one wave-aggregated global atomic per list, counters packed: 124-486 us (32 lists per L2 line);
 //   * counters one line apart, the wave looping over its distinct lists with a returning atomic each:
-//     24 us - ~8 dependent L2 round trips per wave and ~1000 VALU instructions per thread for the
-//     de-duplication of 16 corner tiles.
+//     24 us - ~8 dependent L2 round trips per wave and ~1000 VALU instructions per thread;
+//   * the bounding box of the row's samples instead of the exact tiles: 10 us there, but milliseconds when the
+//     samples of a row are far apart (every tile of the box got the row).
 constexpr int kCtrStride = 32;      // ints between two list counters (one 128-byte line each)
 constexpr int kBinTable = 4096;     // tiles of one level the LDS table covers (more: direct global atomics)
-constexpr int kBinBox = 4;          // tiles of a thread's box binned through the table (more: direct)
 
 template <typename Src, bool TAPS>
 __global__ __launch_bounds__(256) void msda_bin(Src src, TileGeom g, int M, int Lq, int *__restrict__ counter,
@@ -281,23 +282,34 @@ __global__ __launch_bounds__(256) void msda_bin(Src src, TileGeom g, int M, int 
     const bool table = nt <= kBinTable;
     if (table)
         for (int i = threadIdx.x; i < nt; i += 256) s_cnt[i] = 0;
-    int ty0 = 1 << 20, ty1 = -1, tx0 = 1 << 20, tx1 = -1;           // empty box
+    int tile[4 * kP], rank[4 * kP];
+#pragma unroll
+    for (int c = 0; c < 4 * kP; ++c) tile[c] = -1, rank[c] = 0;
     if (live) {
         const int64_t row = ((int64_t)n * Lq + q) * M + m;
         const typename Src::Raw raw = src.template load<false>(row, q, l);
         unsigned orphan = 0;
+        int ya[kP], yb[kP], xa[kP], xb[kP];
+        bool in[kP];
 #pragma unroll
         for (int p = 0; p < kP; ++p) {
             const float2 xy = src.xy(raw, p, H, W);
             const Base b = make_base(xy.x, xy.y, H, W);
-            // corner rows y0, y0 + 1 clipped to the map (y0 >= -1, y0 <= H - 1 when inside)
-            const int ya = max(b.y0, 0) >> kTShY, yb = min(b.y0 + 1, H - 1) >> kTShY;
-            const int xa = max(b.x0, 0) >> kTShX, xb = min(b.x0 + 1, W - 1) >> kTShX;
+            // tile rows / columns of the corner rows y0, y0 + 1 clipped to the map (inside: -1 <= y0 <= H - 1)
+            ya[p] = max(b.y0, 0) >> kTShY, yb[p] = min(b.y0 + 1, H - 1) >> kTShY;
+            xa[p] = max(b.x0, 0) >> kTShX, xb[p] = min(b.x0 + 1, W - 1) >> kTShX;
+            in[p] = b.inside;
             orphan |= b.inside ? 0u : 1u << p;          // no corner anywhere: no tile will own this sample
-            ty0 = b.inside ? min(ty0, ya) : ty0;
-            ty1 = b.inside ? max(ty1, yb) : ty1;
-            tx0 = b.inside ? min(tx0, xa) : tx0;
-            tx1 = b.inside ? max(tx1, xb) : tx1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int tyc = (c >> 1) ? yb[p] : ya[p], txc = (c & 1) ? xb[p] : xa[p];
+                // the block of the sample itself: second row / column only if it is another tile
+                bool fresh = in[p] && ((c >> 1) == 0 || yb[p] != ya[p]) && ((c & 1) == 0 || xb[p] != xa[p]);
+#pragma unroll
+                for (int e = 0; e < kP; ++e)            // not in the block of an earlier sample
+                    if (e < p) fresh = fresh && !(in[e] && tyc >= ya[e] && tyc <= yb[e] && txc >= xa[e] && txc <= xb[e]);
+                tile[p * 4 + c] = fresh ? tyc * ntx + txc : -1;
+            }
         }
         // a sample inside the gate has its corner (max(y0,0), max(x0,0)) in the map, so some tile owns it and writes
         // its gradients; the others (gate failed: spec cuh:288) get their zeros here
@@ -306,39 +318,32 @@ __global__ __launch_bounds__(256) void msda_bin(Src src, TileGeom g, int M, int 
             src.store_grads(row, l, orphan, z, z, z, H, W);
         }
     }
-    const int bw = tx1 - tx0 + 1, bh = ty1 - ty0 + 1;
-    const int ntile = (ty1 >= ty0) ? bw * bh : 0;
     const int64_t list0 = ((int64_t)n * g.T + g.tbase[l]) * M + m;         // + tile * M
     const int64_t ent0 = ((int64_t)n * g.ET + g.ebase[l]) * M + (int64_t)m * cap;      // + tile * cap * M
     __syncthreads();
-    // ---- the first kBinBox tiles of the box through the LDS table
-    int tile_k[kBinBox], rank_k[kBinBox];
+    if (table) {
 #pragma unroll
-    for (int k = 0; k < kBinBox; ++k) {
-        const bool on = table && k < ntile;
-        const int ky = k / max(bw, 1), kx = k - ky * max(bw, 1);
-        tile_k[k] = on ? (ty0 + ky) * ntx + tx0 + kx : -1;
-        rank_k[k] = on ? atomicAdd(&s_cnt[tile_k[k]], 1) : 0;
-    }
-    __syncthreads();
-    if (table)
+        for (int c = 0; c < 4 * kP; ++c)
+            if (tile[c] >= 0) rank[c] = atomicAdd(&s_cnt[tile[c]], 1);
+        __syncthreads();
         for (int i = threadIdx.x; i < nt; i += 256) {
             const int c = s_cnt[i];
             if (c) s_cnt[i] = atomicAdd(counter + (list0 + (int64_t)i * M) * kCtrStride, c);
         }
-    __syncthreads();
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < kBinBox; ++k)
-        if (tile_k[k] >= 0) {
-            const int pos = s_cnt[tile_k[k]] + rank_k[k];
-            if (pos < cap) entries[ent0 + (int64_t)tile_k[k] * cap * M + pos] = q;
-        }
-    // ---- whatever is left (boxes of more than kBinBox tiles, levels of more than kBinTable tiles)
-    for (int k = table ? kBinBox : 0; k < ntile; ++k) {
-        const int ky = k / bw, kx = k - ky * bw;
-        const int t = (ty0 + ky) * ntx + tx0 + kx;
-        const int pos = atomicAdd(counter + (list0 + (int64_t)t * M) * kCtrStride, 1);
-        if (pos < cap) entries[ent0 + (int64_t)t * cap * M + pos] = q;
+        for (int c = 0; c < 4 * kP; ++c)
+            if (tile[c] >= 0) {
+                const int pos = s_cnt[tile[c]] + rank[c];
+                if (pos < cap) entries[ent0 + (int64_t)tile[c] * cap * M + pos] = q;
+            }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4 * kP; ++c)
+            if (tile[c] >= 0) {
+                const int pos = atomicAdd(counter + (list0 + (int64_t)tile[c] * M) * kCtrStride, 1);
+                if (pos < cap) entries[ent0 + (int64_t)tile[c] * cap * M + pos] = q;
+            }
     }
 }
 
@@ -760,9 +765,10 @@ int make_plan(const char *fn, int64_t N, int64_t S, int64_t M, int64_t L, int64_
         g.ntx[l] = (int)((W + kTW - 1) / kTW);
         const int64_t nt = (int64_t)g.ntx[l] * ((H + kTH - 1) / kTH);
         g.tbase[l] = (int)T;
-        // capacity: 4x the load of samples spread evenly over the level (a (q, level) row names ~1.3 tiles
-        // when its samples sit close together, up to 16 when they do not: 2 per row is the mean budgeted)
-        int64_t cap = (4 * 2 * Lq + nt - 1) / nt;
+        // capacity: 12 rows' worth per tile of evenly spread queries (a (q, level) row names ~1.5 tiles when its
+        // samples sit close together - the adapter - and ~5.6 when each sample falls somewhere else - test.py's
+        // uniform recipe: 2x headroom over that)
+        int64_t cap = (12 * Lq + nt - 1) / nt;
         cap = (cap < 128 ? 128 : cap + 63) / 64 * 64;
         if (cap > Lq + 64) cap = (Lq + 63) / 64 * 64;          // a list never holds more than every query
         g.cap[l] = (int)cap;

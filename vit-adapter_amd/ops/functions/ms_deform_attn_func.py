@@ -30,10 +30,9 @@ class MSDeformAttnFunction(Function):
     def forward(ctx, value, value_spatial_shapes, value_level_start_index,
                 sampling_locations, attention_weights, im2col_step):
         ctx.im2col_step = im2col_step
-        ctx.schedule = MSDA.current_schedule()      # optional LDS-window hint, never changes results
         output = MSDA.ms_deform_attn_forward(
             value, value_spatial_shapes, value_level_start_index, sampling_locations,
-            attention_weights, ctx.im2col_step, schedule=ctx.schedule)
+            attention_weights, ctx.im2col_step)
         ctx.save_for_backward(value, value_spatial_shapes, value_level_start_index,
                               sampling_locations, attention_weights)
         return output
@@ -44,8 +43,7 @@ class MSDeformAttnFunction(Function):
     def backward(ctx, grad_output):
         value, shapes, lsi, loc, attn = ctx.saved_tensors
         grad_value, grad_loc, grad_attn = MSDA.ms_deform_attn_backward(
-            value, shapes, lsi, loc, attn, grad_output.contiguous(), ctx.im2col_step,
-            schedule=ctx.schedule)
+            value, shapes, lsi, loc, attn, grad_output.contiguous(), ctx.im2col_step)
         return grad_value, None, None, grad_loc, grad_attn, None
 
 

@@ -30,29 +30,6 @@ except ImportError:                                                     # ops/ u
     def _linear_pair(lin_a, lin_b, x):
         return lin_a(x), lin_b(x)
 
-_SCHEDULES = {}
-
-
-def schedule_for(reference_points, spatial_shapes):
-    """Query schedule for the LDS-windowed kernels, built once per reference-point tensor (one
-    host read of the (L, 2) shape tensor on the first call) and cached.  Only reference grids
-    shared by the whole batch - shape (1, Lq, L, 2), as the adapter builds them - get one."""
-    if not reference_points.is_cuda or reference_points.shape[0] != 1 or reference_points.shape[-1] != 2:
-        return None
-    key = (reference_points.data_ptr(), tuple(reference_points.shape), reference_points._version,
-           spatial_shapes.data_ptr(), str(reference_points.device))
-    hit = _SCHEDULES.get(key)
-    if hit is None:
-        shapes = [tuple(int(v) for v in hw) for hw in spatial_shapes.tolist()]
-        hit = MSDA.build_query_schedule(reference_points, shapes)
-        if len(_SCHEDULES) > 64:
-            _SCHEDULES.clear()
-        # keep the tensors alive so their data_ptr cannot be recycled under the same key
-        _SCHEDULES[key] = (hit, reference_points, spatial_shapes)
-        return hit
-    return hit[0]
-
-
 def _is_power_of_2(n):
     if not isinstance(n, int) or n < 0:
         raise ValueError('invalid input for _is_power_of_2: {} (type: {})'.format(n, type(n)))
@@ -137,7 +114,6 @@ class MSDeformAttn(nn.Module):
         else:
             raise ValueError('Last dim of reference_points must be 2 or 4, but get {} instead.'
                              .format(reference_points.shape[-1]))
-        with MSDA.query_schedule(schedule_for(reference_points, input_spatial_shapes)):
-            out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
-                                             loc, weights, self.im2col_step)
+        out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
+                                         loc, weights, self.im2col_step)
         return _linear(self.output_proj, out)
