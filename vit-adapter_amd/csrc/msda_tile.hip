@@ -33,6 +33,7 @@
 //             (n, head, level) instead and masks them to its tile - slow (Lq / 64 chunks) but exact, and
 //             only reached by sampling patterns that pile > 4x the mean load onto one tile.
 // A list entry is 4 bytes (q); the tile kernel re-reads the entry's locations / weights / grad_out row.
+#include <cstdlib>
 #include <type_traits>
 
 #include "msda_common.h"
@@ -393,7 +394,7 @@ template <typename GT, typename OT, typename Src, bool TAPS>
 __global__ __launch_bounds__(kTileThreads) void msda_tile_gv(Src src, TileGeom g, int M, int64_t Lq, int64_t S,
                                                              const GT *__restrict__ value, const GT *__restrict__ grad_out,
                                                              int *__restrict__ counter,
-                                                             const int *__restrict__ entries, int64_t nwgs, int N,
+                                                             const int *__restrict__ entries, int64_t nwgs, int ablate,
                                                              float *__restrict__ slabs, OT *__restrict__ grad_value) {
     using LD = TileLds<GT>;
     constexpr int WS = LD::WS;
@@ -462,6 +463,7 @@ __global__ __launch_bounds__(kTileThreads) void msda_tile_gv(Src src, TileGeom g
     // (at least one - slice 0 - so that an empty tile is still stored)
     const int nslices = min(ks, max(nchunks, 1));
     if (j >= nslices) return;
+    if ((ablate & 32) && count >= 0) return;                    // timing only: workgroup launch + its first two loads
     constexpr int NV = kD * (int)sizeof(GT) / 16;               // 16-byte pieces of a grad_out row
     const int STEP = ks;
     // Software pipeline, one iteration deep for the operands and two for the list entries: at the top of the
@@ -496,7 +498,7 @@ __global__ __launch_bounds__(kTileThreads) void msda_tile_gv(Src src, TileGeom g
 #pragma unroll
         for (int i = 0; i < NV; ++i) gr[i] = src4[i];
     }
-    for (int ch = j; ch < nchunks; ch += STEP) {
+    for (int ch = j; ch < ((ablate & 64) ? 0 : nchunks); ch += STEP) {
         // ---- requests for the chunks to come
         const bool live_n = live_of(ch + STEP);
         const int64_t row_n = (n * Lq + q_n) * M + m;
@@ -509,7 +511,7 @@ __global__ __launch_bounds__(kTileThreads) void msda_tile_gv(Src src, TileGeom g
         }
         const int64_t q_nn = entry_of(ch + 2 * STEP);
         // ---- the entry's grad_out row -> Gs[lane][0..31] (zeros for the lanes past the list's end)
-        {
+        if (!(ablate & 8)) {
             uint4 *dst4 = reinterpret_cast<uint4 *>(Gs + lane * kD);
 #pragma unroll
             for (int i = 0; i < NV; ++i) dst4[i] = live ? gr[i] : make_uint4(0, 0, 0, 0);
@@ -550,14 +552,16 @@ __global__ __launch_bounds__(kTileThreads) void msda_tile_gv(Src src, TileGeom g
                     wcell[p][c] = Wt + px * WS + lane;
                     wgt[c] = mine[c] ? a[p] * cw[c] : 0.f;
                 }
+                if (!(ablate & 1)) {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) old[c] = *wcell[p][c];
+                    for (int c = 0; c < 4; ++c) old[c] = *wcell[p][c];
 #pragma unroll
-                for (int c = 0; c < 4; ++c) *wcell[p][c] = old[c] + wgt[c];
+                    for (int c = 0; c < 4; ++c) *wcell[p][c] = old[c] + wgt[c];
+                }
                 const bool owned = valid[0] ? mine[0] : valid[1] ? mine[1] : valid[2] ? mine[2] : (valid[3] && mine[3]);
                 own |= owned ? 1u << p : 0u;
                 gx[p] = gy[p] = gav[p] = 0.f;
-                if (TAPS && __ballot(owned)) {                              // wave-uniform: some lane owns its sample p
+                if (TAPS && !(ablate & 4) && __ballot(owned)) {                              // wave-uniform: some lane owns its sample p
                     float d[4];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
@@ -570,11 +574,12 @@ __global__ __launch_bounds__(kTileThreads) void msda_tile_gv(Src src, TileGeom g
                     gx[p] = (hh * (d[1] - d[0]) + b.lh * (d[3] - d[2])) * a[p];
                 }
             }
-            if (TAPS && own) src.store_grads(row, l, own, gx, gy, gav, H, W);
+            if (TAPS && !(ablate & 16) && own) src.store_grads(row, l, own, gx, gy, gav, H, W);
         }
         __builtin_amdgcn_wave_barrier();
         // ---- dV[32 px, 32 ch] += Wt[32 px, 64 k] x G[64 k, 32 ch]
-        if constexpr (F32) {
+        if (ablate & 2) {
+        } else if constexpr (F32) {
             const int r = lane & 31, h = lane >> 5;
 #pragma unroll 8
             for (int kk = 0; kk < 32; ++kk) {
@@ -615,6 +620,7 @@ __global__ __launch_bounds__(kTileThreads) void msda_tile_gv(Src src, TileGeom g
         }
         __builtin_amdgcn_wave_barrier();
         // ---- put the column back to zero (what this lane wrote; the dummy row may hold anything)
+        if (!(ablate & 1))
 #pragma unroll
         for (int p = 0; p < kP; ++p)
 #pragma unroll
@@ -834,8 +840,14 @@ int run_tiled(const char *fn, const Src &src, const Plan &pl, int64_t N, int64_t
     const int smem = TAPS ? TileLds<GT>::per_wave_taps : TileLds<GT>::per_wave_plain;
     if (int rc = allow_dynamic_lds((const void *)msda_tile_gv<GT, OT, Src, TAPS>, smem, fn)) return rc;
     const int64_t grid = (pl.nwgs + 7) / 8 * 8;
+    // VAH_TILE_ABLATE (timing experiments only, results are wrong): bit 0 skips the Wt updates, 1 the matrix phase, 2 the
+    // owned samples' dot products, 3 the grad_out staging, 4 the gradient stores
+    static const int ablate = [] {
+        const char *e = getenv("VAH_TILE_ABLATE");
+        return e ? atoi(e) : 0;
+    }();
     hipLaunchKernelGGL((msda_tile_gv<GT, OT, Src, TAPS>), dim3((unsigned)grid), dim3(kTileThreads), smem, st, src, pl.g, (int)M, Lq, S,
-                       value, grad_out, counts, (const int *)entries, pl.nwgs, (int)N, (float *)(base + pl.off_slabs), grad_value);
+                       value, grad_out, counts, (const int *)entries, pl.nwgs, ablate, (float *)(base + pl.off_slabs), grad_value);
     return check_launch(fn);
 }
 
