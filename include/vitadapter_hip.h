@@ -119,6 +119,26 @@ int vah_msda_fused_backward(const void *value, int value_dtype, const int64_t *s
                             float *grad_value, void *d_offsets, void *d_logits, void *stream);
 
 /* ------------------------------------------------------------------------------------
+ * Fused forward over LDS value windows (csrc/msda_fwd_win.hip), single-level calls (L == 1, D == 32, P == 4,
+ * reference points shared by the batch: the adapter's extractor).  Same result as vah_msda_fused_forward for ANY
+ * offsets; the schedule only decides which corner rows are served from LDS:
+ *   perm       (Lq,)           int32  the queries group by group (a permutation of [0, Lq))
+ *   group_off  (ngroups + 1,)  int32  group g owns perm[group_off[g] .. group_off[g+1])
+ *   group_win  (ngroups, 4)    int32  {y0, x0, h, w}: the window of the value map (inside the map) staged for
+ *                                     the group; corners outside it are read from global memory
+ *   max_win_px                        largest h * w (sizes the LDS: max_win_px * 32 * sizeof(value) <= 64 KB)
+ *   H, W, level_start                 the level's geometry (host values)
+ * A workgroup is (n, group, head): it stages the window once, then one lane per query evaluates its four
+ * samples against it (replaces ms_deform_im2col_cuda.cuh:237-299 + the module's softmax / location lines).
+ * ------------------------------------------------------------------------------------ */
+int vah_msda_fused_forward_win(const void *value, int value_dtype, const void *offsets, const void *logits,
+                               int param_dtype, const float *ref, const int32_t *perm,
+                               const int32_t *group_off, const int32_t *group_win, int64_t ngroups,
+                               int64_t max_win_px, int64_t H, int64_t W, int64_t level_start, int64_t N,
+                               int64_t S, int64_t M, int64_t D, int64_t Lq, int64_t P, void *out,
+                               void *stream);
+
+/* ------------------------------------------------------------------------------------
  * TILED BACKWARD: grad_value without atomics and without a zero-fill, for ANY sampling locations
  * (csrc/msda_tile.hip; replaces the scatter of ms_deform_im2col_cuda.cuh:87-159 as called from
  * :301-403).  One binning pass puts every (n, q, m, level) row into the lists of the 8x4-pixel tiles of the

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -65,6 +65,8 @@ lib.vah_msda_fused_forward.argtypes = [_p, _ci, _p, _p, _p, _p, _ci, _p, _i64] +
 lib.vah_msda_fused_forward.restype = ctypes.c_int
 lib.vah_msda_fused_backward.argtypes = [_p, _ci, _p, _p, _p, _p, _ci, _p, _i64, _p] + [_i64] * 7 + [_p] * 4
 lib.vah_msda_fused_backward.restype = ctypes.c_int
+lib.vah_msda_fused_forward_win.argtypes = [_p, _ci, _p, _p, _ci, _p, _p, _p, _p] + [_i64] * 11 + [_p, _p]
+lib.vah_msda_fused_forward_win.restype = ctypes.c_int
 lib.vah_msda_tile_ws_bytes.argtypes = [_i64] * 6 + [_p, _p]
 lib.vah_msda_tile_ws_bytes.restype = _i64
 lib.vah_msda_backward_tiled_f32.argtypes = [_p] * 6 + [_i64] * 7 + [_p] * 3 + [_p, _p, _p, _i64, _p]
@@ -127,7 +129,7 @@ EXPORTS = (
     'vah_msda_forward_f32', 'vah_msda_forward_f64',
     'vah_msda_backward_f32', 'vah_msda_backward_f64',
     'vah_msda_fused_supported', 'vah_msda_fused_forward', 'vah_msda_fused_backward',
-    'vah_msda_tile_ws_bytes', 'vah_msda_backward_tiled_f32', 'vah_msda_fused_backward_tiled',
+    'vah_msda_fused_forward_win', 'vah_msda_tile_ws_bytes', 'vah_msda_backward_tiled_f32', 'vah_msda_fused_backward_tiled',
     'vah_attn_padded_len', 'vah_attn_fwd_bf16', 'vah_attn_bwd_workspace_bytes', 'vah_attn_bwd_bf16',
     'vah_attn_win_fwd_bf16', 'vah_attn_win_bwd_bf16',
     'vah_reduce_ws_floats', 'vah_layernorm_fwd_f32_bf16', 'vah_layernorm_bwd_f32_bf16', 'vah_scale_residual_fwd',

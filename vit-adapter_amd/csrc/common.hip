@@ -103,7 +103,7 @@ LaunchScope::~LaunchScope() {
 
 extern "C" {
 
-int vah_abi_version(void) { return 27; }
+int vah_abi_version(void) { return 28; }
 
 const char *vah_last_error(void) { return vah::g_err; }
 
