@@ -199,7 +199,9 @@ int vah_attn_fwd_bf16(const void *q, const void *k, const void *v, int64_t ld, i
  * q = k = v rows - the reference pads AFTER the projection - take part in the softmax unmasked and
  * are never written).  No pad / unfold / fold / crop copies.  out uses the same token order.
  * Sequences Z = B * ceil(grid_h/win) * ceil(grid_w/win), N = win*win tokens each:
- * lse is (Z, heads, N), vt_ws holds Z*heads*64*vah_attn_padded_len(N) bf16. */
+ * lse is (Z, heads, N), vt_ws holds Z*heads*64*vah_attn_padded_len(N) bf16.
+ * win*win <= 224 (the reference's 14 x 14 windows): ONE kernel, one workgroup per (window, head) with K and V of the
+ * window resident in LDS (csrc/attn_win.hip); vt_ws is not touched and may be NULL. */
 int vah_attn_win_fwd_bf16(const void *q, const void *k, const void *v, int64_t ld, int64_t B,
                           int64_t grid_h, int64_t grid_w, int64_t win, int64_t H, float scale,
                           void *vt_ws, void *out, int64_t ld_out, float *lse, void *stream);
@@ -216,7 +218,8 @@ int vah_attn_bwd_bf16(const void *q, const void *k, const void *v, int64_t ld, i
                       int64_t B, int64_t H, int64_t N, float scale, void *ws,
                       void *dq, void *dk, void *dv, int64_t ld_d, int64_t batch_stride_d,
                       void *stream);
-/* ws: vah_attn_bwd_workspace_bytes(Z, heads, win*win) bytes. */
+/* ws: vah_attn_bwd_workspace_bytes(Z, heads, win*win) bytes.  win*win <= 224: ONE kernel (delta, dQ, dK, dV; Q, K,
+ * V, dO of the window resident in LDS), ws is not touched and may be NULL; profiler row "attn_win_bwd_bf16". */
 int vah_attn_win_bwd_bf16(const void *q, const void *k, const void *v, int64_t ld,
                           const void *out, const void *dout, int64_t ld_out, const float *lse,
                           int64_t B, int64_t grid_h, int64_t grid_w, int64_t win, int64_t H, float scale,

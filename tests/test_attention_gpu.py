@@ -62,7 +62,9 @@ def test_fp32_and_other_head_dims_use_library_gemms():
     assert (out - _ref(qkv, 32 ** -0.5)).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize('B,H,W,heads,win', [(2, 10, 17, 2, 14), (1, 14, 14, 3, 14), (2, 64, 64, 2, 14), (1, 5, 3, 1, 4)])
+@pytest.mark.parametrize('B,H,W,heads,win', [(2, 10, 17, 2, 14), (1, 14, 14, 3, 14), (2, 64, 64, 2, 14), (1, 5, 3, 1, 4),
+                                                   (1, 9, 20, 1, 8), (1, 11, 10, 2, 10), (1, 13, 25, 1, 12), (1, 13, 14, 1, 13),
+                                                   (1, 7, 13, 2, 6), (1, 20, 33, 1, 16)])
 def test_window_attention_fused_partition(B, H, W, heads, win):
     """Windows cut by the kernels' addressing vs the reference's sequence (pad AFTER projection,
     partition, attend, merge, crop; base/vit.py:136-167) evaluated in fp32."""

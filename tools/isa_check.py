@@ -19,13 +19,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 
 
+def per_file_flags(src):
+    """The extra flags vit-adapter_amd/build.py compiles this file with."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('vah_build', os.path.join(ROOT, 'vit-adapter_amd', 'build.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.PER_FILE_FLAGS.get(os.path.basename(src), [])
+
+
 def main():
     src = os.path.abspath(sys.argv[1])
     pats = [a for a in sys.argv[2:] if not a.startswith('-D')]
     defs = [a for a in sys.argv[2:] if a.startswith('-D')]
     with tempfile.TemporaryDirectory() as tmp:
         cmd = [HIPCC, '--offload-arch=gfx950', '-O3', '-std=c++17', '-ffp-contract=fast', '-I', os.path.join(ROOT, 'include'),
-               '-I', os.path.dirname(src), '-c', src, '-o', os.path.join(tmp, 'x.o'), '-save-temps'] + defs
+               '-I', os.path.dirname(src), '-c', src, '-o', os.path.join(tmp, 'x.o'), '-save-temps'] + defs + per_file_flags(src)
         subprocess.check_call(cmd, cwd=tmp, stderr=subprocess.DEVNULL)
         asm = [f for f in os.listdir(tmp) if f.endswith('gfx950.s')]
         text = open(os.path.join(tmp, asm[0])).read()

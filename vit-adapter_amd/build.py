@@ -22,6 +22,13 @@ FLAGS = ['-O3', '-std=c++17', '--offload-arch=gfx950', '-fPIC', '-Wall', '-Wno-u
          '-ffp-contract=fast']
 
 
+# The attention kernels keep MFMA accumulators that the VALU works on between matrix steps (softmax, dS): with the
+# compiler's default the accumulators live in AGPRs and every such step pays a v_accvgpr_read/write pair per register
+# (190 of 930 instructions in the forward's key loop) and the kernels need 212 - 288 registers (1 - 2 waves per SIMD).
+# Forcing the VGPR form of MFMA removes the copies and brings them to 146 - 202 registers.
+PER_FILE_FLAGS = {f: ['-mllvm', '-amdgpu-mfma-vgpr-form'] for f in ('attn_fwd.hip', 'attn_bwd.hip', 'attn_win.hip', 'attn_flash.hip')}
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True
@@ -40,7 +47,7 @@ def build(force=False, verbose=False):
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + '.o')
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + ['-c', s, '-o', o]
+            cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(os.path.basename(s), []) + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)

@@ -420,6 +420,21 @@ int vah_attn_win_bwd_bf16(const void *q, const void *k, const void *v, int64_t l
     int64_t Z = 0, N = 0;
     if (win < 1) return fail(VAH_E_SHAPE, "%s: win must be >= 1", fn);
     if (int rc = attn::make_rowmap(fn, win, B, grid_h, grid_w, &Z, &N, &rm)) return rc;
+    // windows of <= 224 tokens: one kernel, one workgroup per (window, head), everything resident (attn_win.hip);
+    // ws unused
+    if (N <= 224 && Z >= 1 && Z <= 65535 && H >= 1 && H <= 65535 && ld >= H * attn::kHD && ld_out >= H * attn::kHD &&
+        ld_d >= H * attn::kHD) {
+        if (!q || !k || !v || !out || !dout || !lse || !dq || !dk || !dv) return fail(VAH_E_NULL, "%s: null pointer", fn);
+        if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)dout) % 16 || (ld % 8) || (ld_out % 8) ||
+            ((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv) % 8 || (ld_d % 4))
+            return fail(VAH_E_ALIGN, "%s: q/k/v/out/dout need 16-byte aligned rows, dq/dk/dv 8-byte", fn);
+        // one kernel does the work of the prologue, dq and dkdv kernels: bytes = q, k, v, out, dout in, dq, dk, dv out;
+        // flops (algorithmic) = S, dP, dQ, dK, dV = 10 N^2 64 per (window, head); the kernel forms S and dP twice
+        LaunchScope scope("attn_win_bwd_bf16", 8 * Z * H * N * attn::kHD * 2 + Z * H * N * 4, (hipStream_t)stream, 0,
+                          10 * Z * H * N * N * attn::kHD);
+        return attn::attn_win_bwd_resident(q, k, v, ld, out, dout, ld_out, rm, lse, Z, H, N, scale, dq, dk, dv, ld_d,
+                                           (hipStream_t)stream);
+    }
     return attn_bwd_impl(fn, q, k, v, ld, rm, out, dout, ld_out, lse, Z, H, N, scale, ws, dq, dk, dv, ld_d, stream);
 }
 

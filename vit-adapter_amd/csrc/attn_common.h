@@ -82,6 +82,18 @@ __device__ __forceinline__ int64_t grow(const RowMap &rm, int z, int i, int N) {
 int make_rowmap(const char *fn, int64_t win, int64_t B, int64_t gh, int64_t gw, int64_t *Z, int64_t *N,
                 RowMap *rm);
 
+// attn_flash.hip: whole-sequence forward (rows b * N + i of a (B * N, ld) tensor)
+int attn_fwd_seq(const void *q, const void *k, const void *v, int64_t ld, int64_t B, int64_t H, int64_t N, float scale,
+                 void *out, int64_t ld_out, float *lse, hipStream_t st);
+
+// attn_win.hip: forward with the whole window (N <= 224 tokens) resident in LDS, one workgroup per (window, head)
+int attn_win_fwd_resident(const void *q, const void *k, const void *v, int64_t ld, RowMap rm, int64_t Z, int64_t H,
+                          int64_t N, float scale, void *out, int64_t ld_out, float *lse, hipStream_t st);
+
+int attn_win_bwd_resident(const void *q, const void *k, const void *v, int64_t ld, const void *o, const void *d_o,
+                          int64_t ld_out, RowMap rm, const float *lse, int64_t Z, int64_t H, int64_t N, float scale, void *dq,
+                          void *dk, void *dv, int64_t ld_d, hipStream_t st);
+
 // (rows, heads, 64) strided -> (Z, heads, 64, Np) dense, zero padded beyond N / outside the image.
 // One 64-token tile; `tile` is 64 * kPadRow bf16 of LDS, left holding the (token, d) tile.
 __device__ __forceinline__ void transpose_tile_to_dn(const __bf16 *__restrict__ src, int64_t ld, const RowMap &rm,

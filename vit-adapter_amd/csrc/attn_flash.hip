@@ -1,0 +1,194 @@
+// Global (whole-sequence) attention forward for head_dim 64, bf16 in / fp32 accumulate.
+//
+// Arithmetic of the reference's Attention (/root/reference/detection/mmdet_custom/models/backbones/base/vit.py:
+// 83-88): softmax(q k^T * scale) v.  At head_dim 64 this operator is bound by the VALU, not the matrix pipe: a 32 x 32
+// block of S costs 8 MFMAs (256 cycles) and 16 exp2 + 16 fma + 16 add + max + convert per lane (>= 400 cycles), so
+// the loop below is written to the VALU instruction count (tools/isa_loop_mix.py), not to the MFMA count:
+//   * one specialisation per addressing mode - no window arithmetic (integer divisions) in the key loop;
+//   * K and V tiles row-major in LDS; V^T fragments by ds_read_b64_tr_b16 (no V^T copy, no transpose kernel);
+//   * rows beyond N are CLAMPED to row N - 1 when staged (never zero-filled): their keys are masked to -inf in the
+//     last tile, so P = 0 meets a finite V row;
+//   * the cross-half maximum is one v_permlane32_swap (VALU) instead of a ds_bpermute round trip;
+//   * the running output is rescaled only in iterations where some row's maximum moved (wave-uniform branch).
+#include "attn_common.h"
+#include "common.h"
+
+namespace vah {
+namespace attn {
+namespace {
+
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
+typedef __attribute__((__vector_size__(8 * sizeof(short)))) short s16x8;
+
+__device__ __forceinline__ const __bf16 *tile_lane_base(const __bf16 *tile, int lane) {
+    const int grp = lane >> 4, i16 = lane & 15;
+    return tile + (4 * (grp >> 1) + (i16 >> 2)) * kPadRow + 16 * (grp & 1) + 4 * (i16 & 3);
+}
+// A operand T^T[m = d][k = token] of a row-major LDS tile T[token][d] in the k order of pack_half (attn_win.hip)
+__device__ __forceinline__ bf16x8 load_tr(const __bf16 *base, int tok0, int db) {
+    const __bf16 *p0 = base + tok0 * kPadRow + 32 * db;
+    const s16x4 t0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)p0);
+    const s16x4 t1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3))) *)(p0 + 8 * kPadRow));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(t0, t1, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// Exchange across the two 32-lane halves on the VALU: after v_permlane32_swap a = [x.lo, x.lo], b = [x.hi, x.hi].
+// Inline asm: with the builtin and one value for both operands the compiler folds max(a, b) to a.  The s_nop covers
+// the VALU-write -> permlane-read hazard the compiler would otherwise schedule around.
+__device__ __forceinline__ void swap_halves(float x, float &a, float &b) {
+    a = x;
+    b = x;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float max_halves(float x) {
+    float a, b;
+    swap_halves(x, a, b);
+    return fmaxf(a, b);
+}
+__device__ __forceinline__ float sum_halves(float x) {
+    float a, b;
+    swap_halves(x, a, b);
+    return a + b;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kQB = 128, kKT = 64;
+
+__global__ __launch_bounds__(256) void attn_fwd_seq_kernel(
+    const __bf16 *__restrict__ q, const __bf16 *__restrict__ k, const __bf16 *__restrict__ v, int64_t ld, int N, int H,
+    float scale_log2, __bf16 *__restrict__ out, int64_t ld_out, float *__restrict__ lse) {
+    __shared__ __attribute__((aligned(16))) __bf16 s_k2[2][kKT * kPadRow];
+    __shared__ __attribute__((aligned(16))) __bf16 s_v2[2][kKT * kPadRow];
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, hf = lane >> 5;
+    const int qrow = blockIdx.x * kQB + wave * 32 + r;
+    const int64_t seq0 = (int64_t)b * N;
+    const int64_t gq = seq0 + min(qrow, N - 1);
+
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qf[kk] = *reinterpret_cast<const bf16x8 *>(q + gq * ld + h * kHD + 16 * kk + 8 * hf);
+
+    // staging: 512 pieces of 16 bytes per tile and matrix, two per thread (rows sr and sr + 32)
+    const int sr = threadIdx.x >> 3, sc = (threadIdx.x & 7) * 8;
+    const __bf16 *kp = k + h * kHD + sc, *vp = v + h * kHD + sc;
+    bf16x8 pk0, pk1, pv0, pv1;
+    auto fetch = [&](int key0) {
+        const int64_t g0 = (seq0 + min(key0 + sr, N - 1)) * ld, g1 = (seq0 + min(key0 + sr + 32, N - 1)) * ld;
+        pk0 = *reinterpret_cast<const bf16x8 *>(kp + g0);
+        pk1 = *reinterpret_cast<const bf16x8 *>(kp + g1);
+        pv0 = *reinterpret_cast<const bf16x8 *>(vp + g0);
+        pv1 = *reinterpret_cast<const bf16x8 *>(vp + g1);
+    };
+    auto commit = [&](int buf) {
+        *reinterpret_cast<bf16x8 *>(s_k2[buf] + sr * kPadRow + sc) = pk0;
+        *reinterpret_cast<bf16x8 *>(s_k2[buf] + (sr + 32) * kPadRow + sc) = pk1;
+        *reinterpret_cast<bf16x8 *>(s_v2[buf] + sr * kPadRow + sc) = pv0;
+        *reinterpret_cast<bf16x8 *>(s_v2[buf] + (sr + 32) * kPadRow + sc) = pv1;
+    };
+
+    f32x16 o[2] = {zero16(), zero16()};
+    f32x16 lsum = zero16();
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.f;
+    const f32x2 sc2 = {scale_log2, scale_log2};
+    float m_run = -INFINITY;
+    const int ntiles = (N + kKT - 1) / kKT;
+    fetch(0);
+    commit(0);
+    if (ntiles > 1) fetch(kKT);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();                 // tile t visible; every wave is done with tile t - 1
+        if (t + 1 < ntiles) {
+            commit((t + 1) & 1);
+            if (t + 2 < ntiles) fetch((t + 2) * kKT);
+        }
+        const __bf16 *s_k = s_k2[t & 1];
+        const __bf16 *vbase = tile_lane_base(s_v2[t & 1], lane);
+
+        f32x16 s[2];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            s[kb] = zero16();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                s[kb] = mfma(*reinterpret_cast<const bf16x8 *>(s_k + (kb * 32 + r) * kPadRow + 16 * kk + 8 * hf), qf[kk], s[kb]);
+        }
+        if (t == ntiles - 1) {
+            const int key0 = t * kKT;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (key0 + kb * 32 + crow(i, hf) >= N) s[kb][i] = -INFINITY;
+        }
+        float mx = s[0][0];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
+        mx = max_halves(mx);
+        const float m_new = fmaxf(m_run, mx * scale_log2);
+        if (__builtin_amdgcn_ballot_w64(m_new > m_run)) {                // some row's maximum moved: rescale
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);    // first tile: exp2(-inf) = 0
+            lsum[0] *= alpha;                                             // every row of lsum is the same sum: row 0 is read
+#pragma unroll
+            for (int db = 0; db < 2; ++db)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) o[db][i] *= alpha;
+            m_run = m_new;
+        }
+        // P^T = exp2(S^T scale - m): packed fma (two elements per VALU instruction), one v_exp each
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {
+                f32x2 x = {s[kb][i], s[kb][i + 1]};
+                x = x * sc2 - f32x2{m_run, m_run};
+                s[kb][i] = __builtin_amdgcn_exp2f(x[0]);
+                s[kb][i + 1] = __builtin_amdgcn_exp2f(x[1]);
+            }
+        // O^T += V^T P^T; the row sums of P ride along as a third block whose A operand is all ones (4 MFMAs on a pipe
+        // with slack instead of 32 VALU adds on the pipe that bounds the loop), from the same bf16 P the product uses
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const bf16x8 pf = pack_half(s[kb], sp);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) o[db] = mfma(load_tr(vbase, kb * 32 + 16 * sp, db), pf, o[db]);
+                lsum = mfma(ones, pf, lsum);
+            }
+    }
+
+    const float l_tot = lsum[0];      // the MFMA has summed over all keys: every row of column r is query r's sum
+    const float inv = 1.f / l_tot;
+    if (qrow < N) {
+        __bf16 *op = out + gq * ld_out + (int64_t)h * kHD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = (__bf16)(o[db][4 * g + j] * inv);
+                *reinterpret_cast<bf16x4 *>(op + db * 32 + 8 * g + 4 * hf) = w;
+            }
+        if (hf == 0) lse[((int64_t)b * H + h) * N + qrow] = m_run + log2f(l_tot);
+    }
+}
+
+}  // namespace
+
+int attn_fwd_seq(const void *q, const void *k, const void *v, int64_t ld, int64_t B, int64_t H, int64_t N, float scale,
+                 void *out, int64_t ld_out, float *lse, hipStream_t st) {
+    hipLaunchKernelGGL(attn_fwd_seq_kernel, dim3((unsigned)((N + kQB - 1) / kQB), (unsigned)H, (unsigned)B), dim3(256), 0, st,
+                       (const __bf16 *)q, (const __bf16 *)k, (const __bf16 *)v, ld, (int)N, (int)H,
+                       scale * 1.4426950408889634f, (__bf16 *)out, ld_out, lse);
+    return check_launch("attn_fwd_seq");
+}
+
+}  // namespace attn
+}  // namespace vah

@@ -227,6 +227,15 @@ int vah_attn_win_fwd_bf16(const void *q, const void *k, const void *v, int64_t l
     int64_t Z = 0, N = 0;
     if (win < 1) return fail(VAH_E_SHAPE, "%s: win must be >= 1", fn);
     if (int rc = attn::make_rowmap(fn, win, B, grid_h, grid_w, &Z, &N, &rm)) return rc;
+    // windows of <= 224 tokens: one workgroup per (window, head) with K and V resident (attn_win.hip); vt_ws unused
+    if (N <= 224 && Z >= 1 && Z <= 65535 && H >= 1 && H <= 65535 && ld >= H * attn::kHD && ld_out >= H * attn::kHD) {
+        if (!q || !k || !v || !out || !lse) return fail(VAH_E_NULL, "%s: null pointer", fn);
+        if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 || (ld % 8) || ((uintptr_t)out % 8) || (ld_out % 4))
+            return fail(VAH_E_ALIGN, "%s: q/k/v need 16-byte aligned rows (ld %% 8 == 0), out 8-byte", fn);
+        LaunchScope scope("attn_win_fwd_bf16", 4 * Z * H * N * attn::kHD * 2 + Z * H * N * 4, (hipStream_t)stream, 0,
+                          4 * Z * H * N * N * attn::kHD);
+        return attn::attn_win_fwd_resident(q, k, v, ld, rm, Z, H, N, scale, out, ld_out, lse, (hipStream_t)stream);
+    }
     return attn_fwd_impl(fn, q, k, v, ld, rm, Z, H, N, scale, vt_ws, out, ld_out, lse, stream);
 }
 
@@ -245,6 +254,11 @@ static int attn_fwd_impl(const char *fn, const void *q, const void *k, const voi
         return fail(VAH_E_ALIGN, "%s: q/k/v need 16-byte aligned rows (ld %% 8 == 0), out 8-byte", fn);
     if (N >= (1 << 24)) return fail(VAH_E_SHAPE, "%s: N too large", fn);
     hipStream_t st = (hipStream_t)stream;
+    if (rm.win == 0) {
+        // whole sequences: the lean kernel of attn_flash.hip (no V^T workspace, no transpose launch)
+        LaunchScope scope("attn_fwd_bf16", 4 * B * H * N * kHD * 2 + B * H * N * 4, st, 0, 4 * B * H * N * N * kHD);
+        return attn_fwd_seq(q, k, v, ld, B, H, N, scale, out, ld_out, lse, st);
+    }
     const int Np = (int)vah_attn_padded_len(N);
     {
         LaunchScope scope("attn_transpose_bf16", 2 * B * H * N * kHD * 2, st);

@@ -69,6 +69,9 @@ def _attention_backward(qkv, out, lse, dout, scale):
     return dqkv
 
 
+_RESIDENT_WINDOW = 224    # tokens per window served by the one-kernel resident path (include/vitadapter_hip.h)
+
+
 class _WindowFlashAttention(torch.autograd.Function):
     """bf16 MFMA attention inside win x win windows of a (B, gh, gw) token grid, windows cut by the
     kernels' addressing (no pad / partition / merge / crop copies)."""
@@ -82,11 +85,13 @@ class _WindowFlashAttention(torch.autograd.Function):
         Nw = win * win
         out = torch.empty((B, N, H, hd), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((Z, H, Nw), dtype=torch.float32, device=qkv.device)
-        ws = torch.empty((Z * H * hd * _vah.lib.vah_attn_padded_len(Nw),), dtype=qkv.dtype, device=qkv.device)
+        # windows of <= 224 tokens stay resident in LDS (csrc/attn_win.hip): no V^T workspace
+        ws = (torch.empty((Z * H * hd * _vah.lib.vah_attn_padded_len(Nw),), dtype=qkv.dtype, device=qkv.device)
+              if Nw > _RESIDENT_WINDOW else None)
         base, esz = qkv.data_ptr(), qkv.element_size()
         with torch.cuda.device(qkv.device):
             rc = _vah.lib.vah_attn_win_fwd_bf16(base, base + C * esz, base + 2 * C * esz, 3 * C, B, gh, gw,
-                                                win, H, float(scale), ws.data_ptr(), out.data_ptr(), C,
+                                                win, H, float(scale), ws.data_ptr() if ws is not None else 0, out.data_ptr(), C,
                                                 lse.data_ptr(), _stream(qkv))
         _vah.check(rc, 'vah_attn_win_fwd_bf16')
         ctx.save_for_backward(qkv, out, lse)
@@ -101,12 +106,13 @@ class _WindowFlashAttention(torch.autograd.Function):
         C = H * hd
         dout = dout.contiguous().to(qkv.dtype)
         dqkv = torch.empty_like(qkv)
-        ws = torch.empty((_vah.lib.vah_attn_bwd_workspace_bytes(Z, H, Nw),), dtype=torch.uint8, device=qkv.device)
+        ws = (torch.empty((_vah.lib.vah_attn_bwd_workspace_bytes(Z, H, Nw),), dtype=torch.uint8, device=qkv.device)
+              if Nw > _RESIDENT_WINDOW else None)
         base, dbase, esz = qkv.data_ptr(), dqkv.data_ptr(), qkv.element_size()
         with torch.cuda.device(qkv.device):
             rc = _vah.lib.vah_attn_win_bwd_bf16(
                 base, base + C * esz, base + 2 * C * esz, 3 * C, out.data_ptr(), dout.data_ptr(), C,
-                lse.data_ptr(), B, gh, gw, win, H, scale, ws.data_ptr(), dbase, dbase + C * esz,
+                lse.data_ptr(), B, gh, gw, win, H, scale, ws.data_ptr() if ws is not None else 0, dbase, dbase + C * esz,
                 dbase + 2 * C * esz, 3 * C, _stream(qkv))
         _vah.check(rc, 'vah_attn_win_bwd_bf16')
         return dqkv, None, None, None, None
