@@ -364,6 +364,8 @@ static int attn_bwd_impl(const char *fn, const void *q, const void *k, const voi
         return fail(VAH_E_ALIGN, "%s: misaligned operand", fn);
     if (N >= (1 << 24)) return fail(VAH_E_SHAPE, "%s: N too large", fn);
     hipStream_t st = (hipStream_t)stream;
+    // whole sequences: the lean kernels of attn_flash.hip (no transposed copies; of ws only B*H*N floats for delta)
+    if (rm.win == 0) return attn_bwd_seq(q, k, v, ld, out, dout, ld_out, lse, B, H, N, scale, (float *)ws, dq, dk, dv, ld_d, st);
     const int Np = (int)((N + 63) / 64 * 64);
     const int64_t tsz = B * H * 64 * (int64_t)Np;
     __bf16 *kt = (__bf16 *)ws, *qt = kt + tsz, *dot = qt + tsz;

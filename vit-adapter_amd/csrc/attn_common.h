@@ -86,6 +86,10 @@ int make_rowmap(const char *fn, int64_t win, int64_t B, int64_t gh, int64_t gw, 
 int attn_fwd_seq(const void *q, const void *k, const void *v, int64_t ld, int64_t B, int64_t H, int64_t N, float scale,
                  void *out, int64_t ld_out, float *lse, hipStream_t st);
 
+int attn_bwd_seq(const void *q, const void *k, const void *v, int64_t ld, const void *o, const void *d_o, int64_t ld_out,
+                 const float *lse, int64_t B, int64_t H, int64_t N, float scale, float *delta, void *dq, void *dk, void *dv,
+                 int64_t ld_d, hipStream_t st);
+
 // attn_win.hip: forward with the whole window (N <= 224 tokens) resident in LDS, one workgroup per (window, head)
 int attn_win_fwd_resident(const void *q, const void *k, const void *v, int64_t ld, RowMap rm, int64_t Z, int64_t H,
                           int64_t N, float scale, void *out, int64_t ld_out, float *lse, hipStream_t st);

@@ -1,4 +1,4 @@
-// Global (whole-sequence) attention forward for head_dim 64, bf16 in / fp32 accumulate.
+// Global (whole-sequence) attention forward and backward for head_dim 64, bf16 in / fp32 accumulate.
 //
 // Arithmetic of the reference's Attention (/root/reference/detection/mmdet_custom/models/backbones/base/vit.py:
 // 83-88): softmax(q k^T * scale) v.  At head_dim 64 this operator is bound by the VALU, not the matrix pipe: a 32 x 32
@@ -124,12 +124,14 @@ __global__ __launch_bounds__(256) void attn_fwd_seq_kernel(
                 for (int i = 0; i < 16; ++i)
                     if (key0 + kb * 32 + crow(i, hf) >= N) s[kb][i] = -INFINITY;
         }
-        float mx = s[0][0];
+        // four independent chains (a single chain of 16 dependent v_max3 is latency, not issue, bound)
+        float mq[4];
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
-        mx = max_halves(mx);
+        for (int c = 0; c < 4; ++c) {
+            mq[c] = fmaxf(fmaxf(s[0][4 * c], s[0][4 * c + 1]), fmaxf(s[0][4 * c + 2], s[0][4 * c + 3]));
+            mq[c] = fmaxf(mq[c], fmaxf(fmaxf(s[1][4 * c], s[1][4 * c + 1]), fmaxf(s[1][4 * c + 2], s[1][4 * c + 3])));
+        }
+        const float mx = max_halves(fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3])));
         const float m_new = fmaxf(m_run, mx * scale_log2);
         if (__builtin_amdgcn_ballot_w64(m_new > m_run)) {                // some row's maximum moved: rescale
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);    // first tile: exp2(-inf) = 0
@@ -180,6 +182,230 @@ __global__ __launch_bounds__(256) void attn_fwd_seq_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Backward, whole sequences.  Two kernels (dQ by query block, dK/dV by key block; S and dP are formed in both - the
+// alternative, one pass with dQ accumulated across key blocks, needs 32 x 25 MB of fp32 atomics per call at this
+// shape).  Against the general kernels of attn_bwd.hip: no transposed copies (K^T, Q^T, dO^T come from the row-major
+// LDS tiles by ds_read_b64_tr_b16), so no prologue kernel - delta = rowsum(dO o O) is formed by the dQ kernel for its
+// own queries and handed to the dK/dV kernel through `delta`; no window arithmetic in the loops; staged rows beyond N
+// are clamped, not zero-filled.
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dq_seq_kernel(
+    const __bf16 *__restrict__ q, const __bf16 *__restrict__ k, const __bf16 *__restrict__ v, int64_t ld,
+    const __bf16 *__restrict__ o, const __bf16 *__restrict__ d_o, int64_t ld_out, const float *__restrict__ lse, int N, int H,
+    float scale, float scale_log2, float *__restrict__ delta, __bf16 *__restrict__ dq, int64_t ld_d) {
+    __shared__ __attribute__((aligned(16))) __bf16 s_k2[2][kKT * kPadRow];
+    __shared__ __attribute__((aligned(16))) __bf16 s_v2[2][kKT * kPadRow];
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, hf = lane >> 5;
+    const int qrow = blockIdx.x * kQB + wave * 32 + r;
+    const int64_t seq0 = (int64_t)b * N;
+    const int64_t gq = seq0 + min(qrow, N - 1);
+
+    bf16x8 qf[4], dof[4];
+    float part = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        qf[kk] = *reinterpret_cast<const bf16x8 *>(q + gq * ld + h * kHD + 16 * kk + 8 * hf);
+        dof[kk] = *reinterpret_cast<const bf16x8 *>(d_o + gq * ld_out + h * kHD + 16 * kk + 8 * hf);
+        const bf16x8 of = *reinterpret_cast<const bf16x8 *>(o + gq * ld_out + h * kHD + 16 * kk + 8 * hf);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part += (float)of[j] * (float)dof[kk][j];
+    }
+    const float delta_q = sum_halves(part);
+    const float lse_q = lse[((int64_t)b * H + h) * N + min(qrow, N - 1)];
+    if (hf == 0 && qrow < N) delta[((int64_t)b * H + h) * N + qrow] = delta_q;
+
+    const int sr = threadIdx.x >> 3, sc = (threadIdx.x & 7) * 8;
+    const __bf16 *kp = k + h * kHD + sc, *vp = v + h * kHD + sc;
+    bf16x8 pk0, pk1, pv0, pv1;
+    auto fetch = [&](int key0) {
+        const int64_t g0 = (seq0 + min(key0 + sr, N - 1)) * ld, g1 = (seq0 + min(key0 + sr + 32, N - 1)) * ld;
+        pk0 = *reinterpret_cast<const bf16x8 *>(kp + g0);
+        pk1 = *reinterpret_cast<const bf16x8 *>(kp + g1);
+        pv0 = *reinterpret_cast<const bf16x8 *>(vp + g0);
+        pv1 = *reinterpret_cast<const bf16x8 *>(vp + g1);
+    };
+    auto commit = [&](int buf) {
+        *reinterpret_cast<bf16x8 *>(s_k2[buf] + sr * kPadRow + sc) = pk0;
+        *reinterpret_cast<bf16x8 *>(s_k2[buf] + (sr + 32) * kPadRow + sc) = pk1;
+        *reinterpret_cast<bf16x8 *>(s_v2[buf] + sr * kPadRow + sc) = pv0;
+        *reinterpret_cast<bf16x8 *>(s_v2[buf] + (sr + 32) * kPadRow + sc) = pv1;
+    };
+
+    f32x16 acc[2] = {zero16(), zero16()};
+    const f32x2 sc2 = {scale_log2, scale_log2}, ls2 = {lse_q, lse_q}, de2 = {delta_q, delta_q};
+    const int ntiles = (N + kKT - 1) / kKT;
+    fetch(0);
+    commit(0);
+    if (ntiles > 1) fetch(kKT);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            commit((t + 1) & 1);
+            if (t + 2 < ntiles) fetch((t + 2) * kKT);
+        }
+        const __bf16 *s_k = s_k2[t & 1], *s_v = s_v2[t & 1];
+        const __bf16 *kbase = tile_lane_base(s_k, lane);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                s = mfma(*reinterpret_cast<const bf16x8 *>(s_k + (kb * 32 + r) * kPadRow + 16 * kk + 8 * hf), qf[kk], s);
+                dp = mfma(*reinterpret_cast<const bf16x8 *>(s_v + (kb * 32 + r) * kPadRow + 16 * kk + 8 * hf), dof[kk], dp);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) {                           // dS^T = P^T o (dP^T - delta)
+                const f32x2 x = f32x2{s[i], s[i + 1]} * sc2 - ls2;
+                const f32x2 pr = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
+                const f32x2 ds = pr * (f32x2{dp[i], dp[i + 1]} - de2);
+                s[i] = ds[0];
+                s[i + 1] = ds[1];
+            }
+            if (t == ntiles - 1) {                                      // clamped rows beyond N are real K rows: mask
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    if (t * kKT + kb * 32 + crow(i, hf) >= N) s[i] = 0.f;
+            }
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const bf16x8 pf = pack_half(s, sp);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) acc[db] = mfma(load_tr(kbase, kb * 32 + 16 * sp, db), pf, acc[db]);
+            }
+        }
+    }
+    if (qrow < N) {
+        __bf16 *op = dq + gq * ld_d + (int64_t)h * kHD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 w;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) w[j] = (__bf16)(acc[db][4 * g + j] * scale);
+                *reinterpret_cast<bf16x4 *>(op + db * 32 + 8 * g + 4 * hf) = w;
+            }
+    }
+}
+
+// dK, dV: workgroup = 128 keys (32 per wave), loop over query tiles of 64
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_seq_kernel(
+    const __bf16 *__restrict__ q, const __bf16 *__restrict__ k, const __bf16 *__restrict__ v, int64_t ld,
+    const __bf16 *__restrict__ d_o, int64_t ld_out, const float *__restrict__ lse, const float *__restrict__ delta, int N, int H,
+    float scale, float scale_log2, __bf16 *__restrict__ dk, __bf16 *__restrict__ dv, int64_t ld_d) {
+    __shared__ __attribute__((aligned(16))) __bf16 s_q2[2][kKT * kPadRow];
+    __shared__ __attribute__((aligned(16))) __bf16 s_do2[2][kKT * kPadRow];
+    __shared__ __attribute__((aligned(16))) float s_lse2[2][kKT];
+    __shared__ __attribute__((aligned(16))) float s_delta2[2][kKT];
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, hf = lane >> 5;
+    const int krow = blockIdx.x * kQB + wave * 32 + r;
+    const int64_t seq0 = (int64_t)b * N;
+    const int64_t gk = seq0 + min(krow, N - 1);
+
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        kf[kk] = *reinterpret_cast<const bf16x8 *>(k + gk * ld + h * kHD + 16 * kk + 8 * hf);
+        vf[kk] = *reinterpret_cast<const bf16x8 *>(v + gk * ld + h * kHD + 16 * kk + 8 * hf);
+    }
+    const int sr = threadIdx.x >> 3, sc = (threadIdx.x & 7) * 8;
+    const __bf16 *qp = q + h * kHD + sc, *dop = d_o + h * kHD + sc;
+    const float *lseb = lse + ((int64_t)b * H + h) * N, *delb = delta + ((int64_t)b * H + h) * N;
+    bf16x8 pq0, pq1, pd0, pd1;
+    float plse = 0.f, pdel = 0.f;
+    auto fetch = [&](int q0) {
+        const int64_t r0 = seq0 + min(q0 + sr, N - 1), r1 = seq0 + min(q0 + sr + 32, N - 1);
+        pq0 = *reinterpret_cast<const bf16x8 *>(qp + r0 * ld);
+        pq1 = *reinterpret_cast<const bf16x8 *>(qp + r1 * ld);
+        pd0 = *reinterpret_cast<const bf16x8 *>(dop + r0 * ld_out);
+        pd1 = *reinterpret_cast<const bf16x8 *>(dop + r1 * ld_out);
+        if (threadIdx.x < kKT) {
+            const int n = q0 + threadIdx.x;
+            plse = n < N ? lseb[n] : INFINITY;                  // +inf: p = 0 for queries that do not exist
+            pdel = n < N ? delb[n] : 0.f;
+        }
+    };
+    auto commit = [&](int buf) {
+        *reinterpret_cast<bf16x8 *>(s_q2[buf] + sr * kPadRow + sc) = pq0;
+        *reinterpret_cast<bf16x8 *>(s_q2[buf] + (sr + 32) * kPadRow + sc) = pq1;
+        *reinterpret_cast<bf16x8 *>(s_do2[buf] + sr * kPadRow + sc) = pd0;
+        *reinterpret_cast<bf16x8 *>(s_do2[buf] + (sr + 32) * kPadRow + sc) = pd1;
+        if (threadIdx.x < kKT) {
+            s_lse2[buf][threadIdx.x] = plse;
+            s_delta2[buf][threadIdx.x] = pdel;
+        }
+    };
+
+    f32x16 dkt[2] = {zero16(), zero16()}, dvt[2] = {zero16(), zero16()};
+    const f32x2 sc2 = {scale_log2, scale_log2};
+    const int ntiles = (N + kKT - 1) / kKT;
+    fetch(0);
+    commit(0);
+    if (ntiles > 1) fetch(kKT);
+    for (int t = 0; t < ntiles; ++t) {
+        __syncthreads();
+        if (t + 1 < ntiles) {
+            commit((t + 1) & 1);
+            if (t + 2 < ntiles) fetch((t + 2) * kKT);
+        }
+        const __bf16 *s_q = s_q2[t & 1], *s_do = s_do2[t & 1];
+        const float *s_lse = s_lse2[t & 1], *s_delta = s_delta2[t & 1];
+        const __bf16 *qbase = tile_lane_base(s_q, lane), *dobase = tile_lane_base(s_do, lane);
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                s = mfma(*reinterpret_cast<const bf16x8 *>(s_q + (qb * 32 + r) * kPadRow + 16 * kk + 8 * hf), kf[kk], s);      // S[q][key]
+                dp = mfma(*reinterpret_cast<const bf16x8 *>(s_do + (qb * 32 + r) * kPadRow + 16 * kk + 8 * hf), vf[kk], dp);   // dP[q][key]
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 l4 = *reinterpret_cast<const float4 *>(s_lse + qb * 32 + 8 * g + 4 * hf);
+                const float4 d4 = *reinterpret_cast<const float4 *>(s_delta + qb * 32 + 8 * g + 4 * hf);
+                const f32x2 l01 = {l4.x, l4.y}, l23 = {l4.z, l4.w}, d01 = {d4.x, d4.y}, d23 = {d4.z, d4.w};
+                const f32x2 x0 = f32x2{s[4 * g], s[4 * g + 1]} * sc2 - l01, x1 = f32x2{s[4 * g + 2], s[4 * g + 3]} * sc2 - l23;
+                const f32x2 p0 = {__builtin_amdgcn_exp2f(x0[0]), __builtin_amdgcn_exp2f(x0[1])};
+                const f32x2 p1 = {__builtin_amdgcn_exp2f(x1[0]), __builtin_amdgcn_exp2f(x1[1])};
+                const f32x2 e0 = p0 * (f32x2{dp[4 * g], dp[4 * g + 1]} - d01), e1 = p1 * (f32x2{dp[4 * g + 2], dp[4 * g + 3]} - d23);
+                s[4 * g] = p0[0], s[4 * g + 1] = p0[1], s[4 * g + 2] = p1[0], s[4 * g + 3] = p1[1];            // P
+                dp[4 * g] = e0[0], dp[4 * g + 1] = e0[1], dp[4 * g + 2] = e1[0], dp[4 * g + 3] = e1[1];        // dS
+            }
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                const bf16x8 pf = pack_half(s, sp), dsf = pack_half(dp, sp);
+#pragma unroll
+                for (int db = 0; db < 2; ++db) {
+                    dvt[db] = mfma(load_tr(dobase, qb * 32 + 16 * sp, db), pf, dvt[db]);      // dV^T[d][key] += dO^T P
+                    dkt[db] = mfma(load_tr(qbase, qb * 32 + 16 * sp, db), dsf, dkt[db]);      // dK^T[d][key] += Q^T dS
+                }
+            }
+        }
+    }
+    if (krow < N) {
+        __bf16 *pk = dk + gk * ld_d + (int64_t)h * kHD, *pv = dv + gk * ld_d + (int64_t)h * kHD;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16x4 wk, wv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    wk[j] = (__bf16)(dkt[db][4 * g + j] * scale);
+                    wv[j] = (__bf16)dvt[db][4 * g + j];
+                }
+                *reinterpret_cast<bf16x4 *>(pk + db * 32 + 8 * g + 4 * hf) = wk;
+                *reinterpret_cast<bf16x4 *>(pv + db * 32 + 8 * g + 4 * hf) = wv;
+            }
+    }
+}
+
 }  // namespace
 
 int attn_fwd_seq(const void *q, const void *k, const void *v, int64_t ld, int64_t B, int64_t H, int64_t N, float scale,
@@ -188,6 +414,28 @@ int attn_fwd_seq(const void *q, const void *k, const void *v, int64_t ld, int64_
                        (const __bf16 *)q, (const __bf16 *)k, (const __bf16 *)v, ld, (int)N, (int)H,
                        scale * 1.4426950408889634f, (__bf16 *)out, ld_out, lse);
     return check_launch("attn_fwd_seq");
+}
+
+
+int attn_bwd_seq(const void *q, const void *k, const void *v, int64_t ld, const void *o, const void *d_o, int64_t ld_out,
+                 const float *lse, int64_t B, int64_t H, int64_t N, float scale, float *delta, void *dq, void *dk, void *dv,
+                 int64_t ld_d, hipStream_t st) {
+    const dim3 grid((unsigned)((N + kQB - 1) / kQB), (unsigned)H, (unsigned)B);
+    const float scale_log2 = scale * 1.4426950408889634f;
+    {
+        // useful flops of the whole backward = 2.5x the forward (S, dP, dV, dK, dQ products); both kernels form S and
+        // dP: dq runs 3 products (6 B H N^2 64), dkdv 4 (8 B H N^2 64)
+        LaunchScope scope("attn_bwd_dq_bf16", 6 * B * H * N * kHD * 2, st, 0, 6 * B * H * N * N * kHD);
+        hipLaunchKernelGGL(attn_bwd_dq_seq_kernel, grid, dim3(256), 0, st, (const __bf16 *)q, (const __bf16 *)k,
+                           (const __bf16 *)v, ld, (const __bf16 *)o, (const __bf16 *)d_o, ld_out, lse, (int)N, (int)H, scale,
+                           scale_log2, delta, (__bf16 *)dq, ld_d);
+        if (int rc = check_launch("attn_bwd_dq_seq")) return rc;
+    }
+    LaunchScope scope("attn_bwd_dkdv_bf16", 8 * B * H * N * kHD * 2, st, 0, 8 * B * H * N * N * kHD);
+    hipLaunchKernelGGL(attn_bwd_dkdv_seq_kernel, grid, dim3(256), 0, st, (const __bf16 *)q, (const __bf16 *)k,
+                       (const __bf16 *)v, ld, (const __bf16 *)d_o, ld_out, lse, delta, (int)N, (int)H, scale, scale_log2,
+                       (__bf16 *)dk, (__bf16 *)dv, ld_d);
+    return check_launch("attn_bwd_dkdv_seq");
 }
 
 }  // namespace attn
