@@ -336,6 +336,56 @@ int vah_maxpool3s2_fwd_bf16(const void *x, int64_t planes, int64_t H, int64_t W,
 int vah_maxpool3s2_bwd_bf16(const void *gy, const void *idx, int64_t planes, int64_t H, int64_t W, void *gx,
                             void *stream);
 
+/* ---- 3x3 convolutions of the SpatialPriorModule as implicit GEMMs (csrc/conv.hip) -----------------------------
+ * Replaces nn.Conv2d(k=3, padding=1, stride 1 | 2, bias=False) forward and both gradients of the stem / conv2-4
+ * (adapter_modules.py:217-260), NHWC bf16 operands, fp32 accumulation.
+ * vah_conv_taps_nhwc_bf16 - the gather-GEMM both the forward and the input gradient are instances of:
+ *   out[n][oy*OS + oy0][ox*OS + ox0][co] = sum_t sum_c w[co][t][c] * in[n][oy*S + ty[t]][ox*S + tx[t]][c]
+ *   for oy < ny, ox < nx (input read as zero outside IH x IW).  in (N, IH, IW, Cin), w (Cout, T, Cin), out (N, OH, OW,
+ *   Cout), all bf16; Cin = 16 or a multiple of 64, Cout a multiple of 64; T <= 9 taps, S, OS in {1, 2}; ty / tx are
+ *   HOST arrays of T offsets in [-4, 4].
+ *   forward, stride s:          S = s, T = 9, (ty, tx) = (dy - 1, dx - 1), w = weight.permute(0, 2, 3, 1), OS = 1;
+ *   input gradient, stride 1:   in = dY, (ty, tx) = (1 - dy, 1 - dx), w[ci][t][co] = weight[co][ci][dy][dx];
+ *   input gradient, stride 2:   one call per output parity (a, b): OS = 2, (oy0, ox0) = (a, b), S = 1, taps
+ *                               {dy : dy = a + 1 mod 2} x {dx : ...} with offsets (a + 1 - dy) / 2, (b + 1 - dx) / 2.
+ * vah_conv3x3_dgrad_nhwc_bf16 - the input gradient as ONE launch: gx (N, H, W, Cin) from gy (N, OH, OW, Cout) and
+ *   wt[ci][dy*3 + dx][co] = weight[co][ci][dy][dx] (bf16); stride 2 runs the four output parities as launch slices.
+ * vah_conv3x3_wgrad_nhwc_bf16 - dw[co][dy][dx][c] (fp32, (Cout, 3, 3, Cin)) = sum_pixels dy[p][co] x[p*S + tap - 1][c];
+ *   ws: vah_conv3x3_wgrad_ws_floats(Cin, Cout) floats (per-workgroup partials, summed in a fixed order). */
+int vah_conv_taps_nhwc_bf16(const void *in, int64_t N, int64_t IH, int64_t IW, int64_t Cin, const void *w, int64_t Cout,
+                            int T, const int *ty, const int *tx, int S, void *out, int64_t ny, int64_t nx, int64_t OH,
+                            int64_t OW, int OS, int oy0, int ox0, void *stream);
+int vah_conv3x3_dgrad_nhwc_bf16(const void *gy, int64_t N, int64_t OH, int64_t OW, int64_t Cout, const void *wt, int64_t Cin,
+                                int S, void *gx, int64_t H, int64_t W, void *stream);
+int64_t vah_conv3x3_wgrad_ws_floats(int64_t Cin, int64_t Cout);
+int vah_conv3x3_wgrad_nhwc_bf16(const void *x, int64_t N, int64_t IH, int64_t IW, int64_t Cin, const void *dy, int64_t OH,
+                                int64_t OW, int64_t Cout, int S, float *ws, int64_t ws_floats, float *dw, void *stream);
+
+/* ---- memory-bound operators of the SpatialPriorModule on NHWC bf16 (csrc/spm_nhwc.hip) -----------------------
+ * The layout the convolutions above read and write: no NCHW <-> NHWC conversion anywhere in the module, and its
+ * stride-8/16/32 outputs ARE the token rows the adapter consumes.
+ * vah_image_to_nhwc16_bf16: x (N, 3, H, W) fp32 -> y (N, H, W, 16) bf16, channels 3..15 zero.
+ * BatchNorm(+ReLU) over the rows of x (rows = N*H*W, C a power of two <= 256), training statistics:
+ *   stats      sums[2C] = [sum x | sum x^2]            (ws: vah_bn_nhwc_ws_floats(C); fixed summation order)
+ *   apply      y = [relu](x * rstd * w + b - mean * rstd * w)   (mean, rstd from vah_bn_finalize_stats)
+ *   bwd_stats  sums[2C] = [sum g' | sum g' xhat], g' = dy where the forward output was positive (all of dy if !relu)
+ *   bwd_apply  dx = w rstd (g' - mean_g - xhat mean_gx)
+ * vah_maxpool3s2_nhwc_*: MaxPool2d(3, stride 2, padding 1) of the stem; idx (same shape as y, one byte per element) =
+ *   window position 0..8 of the first maximum; the backward gathers (no atomics). */
+int vah_image_to_nhwc16_bf16(const float *x, int64_t N, int64_t H, int64_t W, void *y, void *stream);
+int64_t vah_bn_nhwc_ws_floats(int64_t C);
+int vah_bn_nhwc_stats(const void *x, int64_t rows, int64_t C, float *sums, float *ws, void *stream);
+int vah_bn_nhwc_apply(const void *x, int64_t rows, int64_t C, const float *mean, const float *rstd, const float *w,
+                      const float *b, int relu, void *y, void *stream);
+int vah_bn_nhwc_bwd_stats(const void *x, const void *dy, int64_t rows, int64_t C, const float *mean, const float *rstd,
+                          const float *w, const float *b, int relu, float *sums, float *ws, void *stream);
+int vah_bn_nhwc_bwd_apply(const void *x, const void *dy, int64_t rows, int64_t C, const float *mean, const float *rstd,
+                          const float *w, const float *b, int relu, const float *mean_g, const float *mean_gx, void *dx,
+                          void *stream);
+int vah_maxpool3s2_nhwc_fwd_bf16(const void *x, int64_t N, int64_t H, int64_t W, int64_t C, void *y, void *idx, void *stream);
+int vah_maxpool3s2_nhwc_bwd_bf16(const void *gy, const void *idx, int64_t N, int64_t H, int64_t W, int64_t C, void *gx,
+                                 void *stream);
+
 /* ---- bf16 GEMMs of the Linear layers (csrc/gemm.hip) ----------------------------------------
  * D (M x N, row-major, leading dimension ldd; bf16, or fp32 when d_is_f32) = op(A) op(B), bf16
  * operands, fp32 accumulation.  trans_a: A is stored (K x M) row-major and used transposed;

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -105,6 +105,21 @@ lib.vah_bn_tail_bwd_apply.argtypes = _tail_in + [_p, _p, _p, _p, _int, _p, _p, _
 lib.vah_bn_finalize_stats.argtypes = [_p, _i64, _f, _f, _p, _p, _p, _p, _p]
 lib.vah_maxpool3s2_fwd_bf16.argtypes = [_p, _i64, _i64, _i64, _p, _p, _p]
 lib.vah_maxpool3s2_bwd_bf16.argtypes = [_p, _p, _i64, _i64, _i64, _p, _p]
+lib.vah_conv_taps_nhwc_bf16.argtypes = [_p, _i64, _i64, _i64, _i64, _p, _i64, _int, _p, _p, _int, _p, _i64, _i64, _i64, _i64, _int, _int,
+                                        _int, _p]
+lib.vah_conv3x3_dgrad_nhwc_bf16.argtypes = [_p, _i64, _i64, _i64, _i64, _p, _i64, _int, _p, _i64, _i64, _p]
+lib.vah_conv3x3_wgrad_ws_floats.argtypes = [_i64, _i64]
+lib.vah_conv3x3_wgrad_ws_floats.restype = _i64
+lib.vah_conv3x3_wgrad_nhwc_bf16.argtypes = [_p, _i64, _i64, _i64, _i64, _p, _i64, _i64, _i64, _int, _p, _i64, _p, _p]
+lib.vah_image_to_nhwc16_bf16.argtypes = [_p, _i64, _i64, _i64, _p, _p]
+lib.vah_bn_nhwc_ws_floats.argtypes = [_i64]
+lib.vah_bn_nhwc_ws_floats.restype = _i64
+lib.vah_bn_nhwc_stats.argtypes = [_p, _i64, _i64, _p, _p, _p]
+lib.vah_bn_nhwc_apply.argtypes = [_p, _i64, _i64, _p, _p, _p, _p, _int, _p, _p]
+lib.vah_bn_nhwc_bwd_stats.argtypes = [_p, _p, _i64, _i64, _p, _p, _p, _p, _int, _p, _p, _p]
+lib.vah_bn_nhwc_bwd_apply.argtypes = [_p, _p, _i64, _i64, _p, _p, _p, _p, _int, _p, _p, _p, _p]
+lib.vah_maxpool3s2_nhwc_fwd_bf16.argtypes = [_p, _i64, _i64, _i64, _i64, _p, _p, _p]
+lib.vah_maxpool3s2_nhwc_bwd_bf16.argtypes = [_p, _p, _i64, _i64, _i64, _i64, _p, _p]
 lib.vah_transpose_tokens.argtypes = [_p, _i64, _i64, _i64, _i64, _i64, _p, _int, _int, _p, _p]
 lib.vah_reduce_ws_floats.argtypes = [_i64]
 lib.vah_reduce_ws_floats.restype = _i64
@@ -116,7 +131,10 @@ for _n in ('vah_layernorm_fwd_f32_bf16', 'vah_layernorm_bwd_f32_bf16', 'vah_scal
            'vah_scale_residual_bwd', 'vah_dwconv3x3_tokens_bf16', 'vah_dwconv3x3_tokens_wgrad_bf16',
            'vah_colsum_bf16', 'vah_colsum_f32', 'vah_layernorm_dual_fwd', 'vah_layernorm_dual_bwd', 'vah_residual_layernorm_fwd', 'vah_residual_layernorm_bwd', 'vah_gemm_set_tuning', 'vah_gemm_bf16', 'vah_gemm_bf16_fin', 'vah_colsum_bf16_partials', 'vah_gemm_table_load',
            'vah_bn_tail_stats', 'vah_bn_tail_apply', 'vah_bn_tail_bwd_stats', 'vah_bn_tail_bwd_apply',
-           'vah_bn_finalize_stats', 'vah_transpose_tokens', 'vah_maxpool3s2_fwd_bf16', 'vah_maxpool3s2_bwd_bf16'):
+           'vah_bn_finalize_stats', 'vah_transpose_tokens', 'vah_maxpool3s2_fwd_bf16', 'vah_maxpool3s2_bwd_bf16',
+           'vah_conv_taps_nhwc_bf16', 'vah_conv3x3_dgrad_nhwc_bf16', 'vah_conv3x3_wgrad_nhwc_bf16',
+           'vah_image_to_nhwc16_bf16', 'vah_bn_nhwc_stats', 'vah_bn_nhwc_apply', 'vah_bn_nhwc_bwd_stats', 'vah_bn_nhwc_bwd_apply',
+           'vah_maxpool3s2_nhwc_fwd_bf16', 'vah_maxpool3s2_nhwc_bwd_bf16'):
     getattr(lib, _n).restype = ctypes.c_int
 
 if lib.vah_abi_version() != ABI_VERSION:
@@ -139,6 +157,9 @@ EXPORTS = (
     'vah_gemm_set_tuning', 'vah_gemm_bf16', 'vah_gemm_bf16_fin', 'vah_colsum_bf16_partials', 'vah_gemm_table_dump', 'vah_gemm_table_load', 'vah_gemm_library_version',
     'vah_bn_tail_ws_floats', 'vah_bn_tail_stats', 'vah_bn_tail_apply', 'vah_bn_tail_bwd_stats', 'vah_bn_tail_bwd_apply',
     'vah_bn_finalize_stats', 'vah_transpose_tokens', 'vah_maxpool3s2_fwd_bf16', 'vah_maxpool3s2_bwd_bf16',
+    'vah_image_to_nhwc16_bf16', 'vah_bn_nhwc_ws_floats', 'vah_bn_nhwc_stats', 'vah_bn_nhwc_apply', 'vah_bn_nhwc_bwd_stats',
+    'vah_bn_nhwc_bwd_apply', 'vah_maxpool3s2_nhwc_fwd_bf16', 'vah_maxpool3s2_nhwc_bwd_bf16',
+    'vah_conv_taps_nhwc_bf16', 'vah_conv3x3_dgrad_nhwc_bf16', 'vah_conv3x3_wgrad_ws_floats', 'vah_conv3x3_wgrad_nhwc_bf16',
 )
 
 

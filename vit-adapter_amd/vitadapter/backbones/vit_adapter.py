@@ -16,7 +16,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from ops.modules import MSDeformAttn
 
-from .. import fused
+from .. import fused, spm_nhwc
 from .adapter_modules import InteractionBlock, SpatialPriorModule, deform_inputs
 from .vit import TIMMVisionTransformer
 
@@ -125,7 +125,10 @@ class ViTAdapter(TIMMVisionTransformer):
 
         # fused tail: the biases of spm.fc1 and self.up reach norm1 as a per-channel shift
         fold = self.add_vit_feature and fused.tail_takes_conv_bias(self.norm1, x)
-        if fused.ENABLED['maps'] and fused.ENABLED['maps_in'] and x.is_cuda:
+        if fold and spm_nhwc.usable(self.spm, x) and not (self.spm.with_cp and x.requires_grad):
+            # the whole module on NHWC bf16 with its own convolution kernels; its stride-8/16/32 maps are the token rows
+            c1, c = spm_nhwc.forward(self.spm, x, self.level_embed)
+        elif fused.ENABLED['maps'] and fused.ENABLED['maps_in'] and x.is_cuda:
             # c2..c4 leave the SPM as bias-free maps; bias + level embedding are added while the token
             # sequence is laid out (one pass per map instead of bias add, level add and cat)
             c1, m2, m3, m4 = self.spm(x, bias_free_c1=fold, raw_maps=True)

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 import _vah
 
 ENABLED = {'layer_norm': True, 'residual': True, 'residual_ln': True, 'dwconv': True, 'linear': True, 'bn_tail': True,
-           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True, 'maps_in': True, 'linear_pair': True, 'maxpool': True, 'conv1x1': True, 'ln_dual': True, 'wgrad_fin': True}
+           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True, 'maps_in': True, 'linear_pair': True, 'maxpool': True, 'conv1x1': True, 'ln_dual': True, 'wgrad_fin': True, 'spm_nhwc': True}
 for _k in os.environ.get('VAH_FUSED_DISABLE', '').split(','):      # e.g. VAH_FUSED_DISABLE=residual_ln,bn_tail (A/B runs)
     if _k:
         ENABLED[_k.strip()] = False
