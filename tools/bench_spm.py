@@ -24,6 +24,22 @@ def main():
             outs = spm(x)
         sum(o.float().sum() for o in outs).backward()
     print('SPM fwd+bwd %.1f us' % (timeit(step, iters=10, warm=5) * 1e6))
+    import _vah
+    from vitadapter import fused, spm_nhwc
+    level = torch.zeros(3, 768, device='cuda', requires_grad=True)
+
+    def step_nhwc():
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            with fused.forward_epoch(spm):
+                c1, c = spm_nhwc.forward(spm, x, level)
+        (c1.float().sum() + c.sum()).backward()
+    step_nhwc()
+    _vah.prof_enable(True, 'spm_,conv_,gemm_,colsum')
+    print('SPM NHWC fwd+bwd %.1f us' % (timeit(step_nhwc, iters=10, warm=3) * 1e6))
+    rep = _vah.prof_report()
+    _vah.prof_enable(False)
+    for name, row in sorted(rep.items(), key=lambda kv: -kv[1]['total_ms']):
+        print('   %-22s calls/step %5.1f  avg %7.1f us  %7.1f us/step' % (name, row['calls'] / 13, row['total_ms'] / row['calls'] * 1e3, row['total_ms'] / 13 * 1e3))
     from vitadapter import conv
     for cin, cout, hw, stride in [(16, 64, 1024, 2), (64, 64, 512, 1), (64, 128, 256, 2), (128, 256, 128, 2), (256, 256, 64, 2)]:
         xi = torch.randn(2, hw, hw, cin, device='cuda').to(torch.bfloat16)

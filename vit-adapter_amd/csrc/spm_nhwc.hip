@@ -22,7 +22,7 @@ namespace {
 
 using attn::bf16x8;
 
-constexpr int kStatParts = 1024;        // partial rows of the statistics passes
+constexpr int kStatParts = 512;         // partial rows of the statistics passes (two workgroups per CU)
 
 __global__ __launch_bounds__(256) void image_to_nhwc16_kernel(const float *__restrict__ x, int64_t HW, int64_t total,
                                                               __bf16 *__restrict__ y) {
@@ -73,8 +73,8 @@ __global__ __launch_bounds__(256) void bn_nhwc_stats_kernel(const __bf16 *__rest
     for (int j = 0; j < 8; ++j) a[j] = b[j] = 0.f;
     // contiguous slab of rows per workgroup
     const int64_t per = (rows + gridDim.x - 1) / gridDim.x, r0 = per * blockIdx.x, r1 = r0 + per < rows ? r0 + per : rows;
-    for (int64_t r = r0 + rl; r < r1; r += RL) {
-        const bf16x8 xv = *reinterpret_cast<const bf16x8 *>(x + r * C + c0);
+    // 4 rows per step: the loads of a step are independent and in flight together
+    auto add = [&](const bf16x8 &xv, const bf16x8 &gv) {
         if (MODE == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -83,7 +83,6 @@ __global__ __launch_bounds__(256) void bn_nhwc_stats_kernel(const __bf16 *__rest
                 b[j] += v * v;
             }
         } else {
-            const bf16x8 gv = *reinterpret_cast<const bf16x8 *>(dy + r * C + c0);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float v = (float)xv[j];
@@ -92,6 +91,23 @@ __global__ __launch_bounds__(256) void bn_nhwc_stats_kernel(const __bf16 *__rest
                 b[j] += g * (v - mu[j]) * rs[j];
             }
         }
+    };
+    int64_t r = r0 + rl;
+    for (; r + 3 * RL < r1; r += 4 * RL) {
+        bf16x8 xv[4], gv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            xv[u] = *reinterpret_cast<const bf16x8 *>(x + (r + u * RL) * C + c0);
+            if (MODE == 1) gv[u] = *reinterpret_cast<const bf16x8 *>(dy + (r + u * RL) * C + c0);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) add(xv[u], gv[u]);
+    }
+    for (; r < r1; r += RL) {
+        const bf16x8 xv = *reinterpret_cast<const bf16x8 *>(x + r * C + c0);
+        bf16x8 gv = xv;
+        if (MODE == 1) gv = *reinterpret_cast<const bf16x8 *>(dy + r * C + c0);
+        add(xv, gv);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) s_red[threadIdx.x][j] = a[j], s_red[threadIdx.x][8 + j] = b[j];
@@ -105,19 +121,31 @@ __global__ __launch_bounds__(256) void bn_nhwc_stats_kernel(const __bf16 *__rest
     }
 }
 
+// out[k] = sum over the partial rows, 32 columns x 8 part lanes per workgroup: lane l adds rows l, l + 8, ... in four
+// independent chains (one serial chain over all rows is a latency-bound tail longer than the pass itself), the 8 lanes
+// are added in order
 __global__ __launch_bounds__(256) void bn_nhwc_sum_parts(const float *__restrict__ part, int nparts, int K, float *__restrict__ out) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
+    __shared__ float s_p[8][33];
+    const int col = threadIdx.x & 31, pl = threadIdx.x >> 5, k = blockIdx.x * 32 + col;
     float s[4] = {0.f, 0.f, 0.f, 0.f};
-    int i = 0;
-    for (; i + 3 < nparts; i += 4) {
-        s[0] += part[(int64_t)i * K + k];
-        s[1] += part[(int64_t)(i + 1) * K + k];
-        s[2] += part[(int64_t)(i + 2) * K + k];
-        s[3] += part[(int64_t)(i + 3) * K + k];
+    if (k < K) {
+        int i = pl;
+        for (; i + 24 < nparts; i += 32) {
+            s[0] += part[(int64_t)i * K + k];
+            s[1] += part[(int64_t)(i + 8) * K + k];
+            s[2] += part[(int64_t)(i + 16) * K + k];
+            s[3] += part[(int64_t)(i + 24) * K + k];
+        }
+        for (; i < nparts; i += 8) s[0] += part[(int64_t)i * K + k];
     }
-    for (; i < nparts; ++i) s[0] += part[(int64_t)i * K + k];
-    out[k] = (s[0] + s[1]) + (s[2] + s[3]);
+    s_p[pl][col] = (s[0] + s[1]) + (s[2] + s[3]);
+    __syncthreads();
+    if (pl == 0 && k < K) {
+        float t = 0.f;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) t += s_p[l][col];
+        out[k] = t;
+    }
 }
 
 __global__ __launch_bounds__(256) void bn_nhwc_apply_kernel(const __bf16 *__restrict__ x, int64_t pieces, int C, BnParams p,
@@ -285,7 +313,7 @@ int vah_bn_nhwc_stats(const void *x, int64_t rows, int64_t C, float *sums, float
     hipLaunchKernelGGL(bn_nhwc_stats_kernel<0>, dim3(parts), dim3(256), 0, st, (const __bf16 *)x, (const __bf16 *)nullptr, rows,
                        (int)C, BnParams{}, 0, ws);
     if (int rc = check_launch(fn)) return rc;
-    hipLaunchKernelGGL(bn_nhwc_sum_parts, dim3((unsigned)((2 * C + 255) / 256)), dim3(256), 0, st, (const float *)ws, parts,
+    hipLaunchKernelGGL(bn_nhwc_sum_parts, dim3((unsigned)((2 * C + 31) / 32)), dim3(256), 0, st, (const float *)ws, parts,
                        (int)(2 * C), sums);
     return check_launch(fn);
 }
@@ -319,7 +347,7 @@ int vah_bn_nhwc_bwd_stats(const void *x, const void *dy, int64_t rows, int64_t C
     hipLaunchKernelGGL(bn_nhwc_stats_kernel<1>, dim3(parts), dim3(256), 0, st, (const __bf16 *)x, (const __bf16 *)dy, rows, (int)C,
                        BnParams{mean, rstd, w, b}, relu, ws);
     if (int rc = check_launch(fn)) return rc;
-    hipLaunchKernelGGL(bn_nhwc_sum_parts, dim3((unsigned)((2 * C + 255) / 256)), dim3(256), 0, st, (const float *)ws, parts,
+    hipLaunchKernelGGL(bn_nhwc_sum_parts, dim3((unsigned)((2 * C + 31) / 32)), dim3(256), 0, st, (const float *)ws, parts,
                        (int)(2 * C), sums);
     return check_launch(fn);
 }

@@ -11,7 +11,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from ops.modules import MSDeformAttn
 
-from .. import fused
+from .. import fused, spm_nhwc
 from .adapter_modules import InteractionBlockWithCls, SpatialPriorModule, deform_inputs
 from .beit import BEiT
 from .vit_adapter import ViTAdapter
@@ -70,7 +70,9 @@ class BEiTAdapter(BEiT):
 
         # fused tail: the biases of spm.fc1 and self.up reach norm1 as a per-channel shift
         fold = self.add_vit_feature and fused.tail_takes_conv_bias(self.norm1, x)
-        if fused.ENABLED['maps'] and fused.ENABLED['maps_in'] and x.is_cuda:
+        if fold and spm_nhwc.usable(self.spm, x) and not (self.spm.with_cp and x.requires_grad):
+            c1, c = spm_nhwc.forward(self.spm, x, self.level_embed)
+        elif fused.ENABLED['maps'] and fused.ENABLED['maps_in'] and x.is_cuda:
             # c2..c4 leave the SPM as bias-free maps; bias + level embedding are added while the token
             # sequence is laid out (one pass per map instead of bias add, level add and cat)
             c1, m2, m3, m4 = self.spm(x, bias_free_c1=fold, raw_maps=True)
