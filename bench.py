@@ -348,7 +348,7 @@ def main():
 
     import _vah
     from vitadapter import data_parallel as dp
-    from vitadapter.backbones.vit_adapter import PRESETS, ViTAdapter
+    from vitadapter.backbones.vit_adapter import PRESETS, build_preset
 
     rank, local_rank, world = dp.init_from_env(args.backend)
     assert world == args.gpus, '--gpus %d but the launcher started %d rank(s)' % (args.gpus, world)
@@ -356,7 +356,7 @@ def main():
     setup_gemm_tuning(args)
     preset_kw = dict(PRESETS[args.preset])
     torch.manual_seed(0)
-    model = ViTAdapter(**preset_kw).to(dev).train()
+    model = build_preset(args.preset).to(dev).train()
     n_params = sum(p.numel() for p in model.parameters())
     net = dp.wrap(model, dev, bucket_cap_mb=64)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.05, fused=True)
@@ -415,7 +415,8 @@ def main():
         if args.boundary_iters > 0 and world == 1:
             kernels.update(boundary_kernels(dev, args.boundary_iters))
         line = {
-            'metric': 'images/sec ViT-Adapter-B 1024x1024 fwd+bwd (+AdamW step)',
+            'metric': ('images/sec ViT-Adapter-B 1024x1024 fwd+bwd (+AdamW step)' if (args.preset, H, W) == ('base_det', 1024, 1024)
+                       else 'images/sec %s %dx%d fwd+bwd (+AdamW step)' % (args.preset, H, W)),
             'value': round(ips, 3), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(1e3 * dt / args.steps, 3),
             'host_enqueue_ms_per_step': round(1e3 * host_dt / args.steps, 3),

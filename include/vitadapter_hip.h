@@ -218,6 +218,29 @@ int vah_attn_bwd_bf16(const void *q, const void *k, const void *v, int64_t ld, i
                       int64_t B, int64_t H, int64_t N, float scale, void *ws,
                       void *dq, void *dk, void *dv, int64_t ld_d, int64_t batch_stride_d,
                       void *stream);
+/* Attention with an additive bias per (head, query, key) - BEiT's relative position bias and class token
+ * (segmentation/mmseg_custom/models/backbones/base/beit.py:120-144: softmax(q k^T * scale + bias) v).
+ * bias: bf16 (heads, N, ldb), the bias TIMES log2(e), ldb a multiple of 64 >= N (columns beyond N ignored);
+ * bias_t: the same matrix transposed per head ((heads, N keys, ldb queries)); ds_out (B, heads, N, ldb) bf16 receives
+ * d loss / d bias of every image (sum over B = the bias gradient; columns beyond N undefined);
+ * delta_ws: B * heads * N floats.  Same kernels as vah_attn_*_bf16 (csrc/attn_flash.hip). */
+int vah_attn_bias_fwd_bf16(const void *q, const void *k, const void *v, int64_t ld, int64_t batch_stride, int64_t B, int64_t H,
+                           int64_t N, float scale, const void *bias, int64_t ldb, void *out, int64_t ld_out, float *lse,
+                           void *stream);
+int vah_attn_bias_bwd_bf16(const void *q, const void *k, const void *v, int64_t ld, int64_t batch_stride, const void *out,
+                           const void *dout, int64_t ld_out, const float *lse, int64_t B, int64_t H, int64_t N, float scale,
+                           const void *bias, const void *bias_t, int64_t ldb, void *ds_out, float *delta_ws, void *dq, void *dk,
+                           void *dv, int64_t ld_d, int64_t batch_stride_d, void *stream);
+/* BEiT's relative position bias around those two calls (csrc/relpos.hip; base/beit.py:120-131):
+ * vah_relpos_bias_build: bias[h][i][j] = table[index[i][j]][h] * log2(e) as bf16 (heads, N, ldb) and its per-head
+ *   transpose - the `bias` / `bias_t` operands above - from the (T, heads) fp32 table and the (N, N) int64 index;
+ * vah_relpos_bias_grad: dtable (T, heads) fp32 = the scatter of sum_B ds_out back through the index
+ *   (ws: vah_relpos_bias_grad_ws_floats(T, heads); LDS-bin accumulation: reproducible to fp32 rounding, not bitwise). */
+int vah_relpos_bias_build(const float *table, const int64_t *index, int64_t T, int64_t H, int64_t N, int64_t ldb, void *bias,
+                          void *bias_t, void *stream);
+int64_t vah_relpos_bias_grad_ws_floats(int64_t T, int64_t H);
+int vah_relpos_bias_grad(const void *ds, const int64_t *index, int64_t B, int64_t H, int64_t N, int64_t ldb, int64_t T, float *ws,
+                         float *dtable, void *stream);
 /* ws: vah_attn_bwd_workspace_bytes(Z, heads, win*win) bytes.  win*win <= 224: ONE kernel (delta, dQ, dK, dV; Q, K,
  * V, dO of the window resident in LDS), ws is not touched and may be NULL; profiler row "attn_win_bwd_bf16". */
 int vah_attn_win_bwd_bf16(const void *q, const void *k, const void *v, int64_t ld,

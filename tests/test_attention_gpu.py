@@ -91,3 +91,60 @@ def test_window_attention_fused_partition(B, H, W, heads, win):
     assert (out.float() - ref).abs().max().item() <= 3e-2 * max(1.0, ref.abs().max().item())
     gerr = (qkv.grad.float() - qr.grad.view_as(qkv)).abs().max().item()
     assert gerr <= 6e-2 * max(1.0, qr.grad.abs().max().item()), gerr
+
+
+@pytest.mark.parametrize('B,N,H', [(1, 64, 1), (2, 197, 3), (1, 130, 2), (2, 1601, 2), (3, 5, 1)])
+def test_attention_with_bias_forward_backward(B, N, H):
+    """softmax(q k^T * scale + bias) v with a (heads, N, N) bias shared by the batch - BEiT's relative position bias
+    and class token (segmentation/mmseg_custom/models/backbones/base/beit.py:120-144) - against the fp32 expression on
+    the same bf16 q, k, v: output, d(qkv) and d(bias).  The bias enters the kernels as bf16: tolerances as the unbiased
+    test, d(bias) (a sum over the batch of dS, written per image in bf16) within 2e-2 of its largest entry."""
+    from vitadapter import kernels
+    torch.manual_seed(N + H)
+    qkv = (torch.randn(B, N, 3, H, 64, device='cuda') * 1.5).to(torch.bfloat16).requires_grad_(True)
+    bias = (torch.randn(H, N, N, device='cuda') * 1.5).requires_grad_(True)
+    scale = 64 ** -0.5
+    out = kernels.attention_bias(qkv, bias, scale)
+    assert out is not None and out.dtype == torch.bfloat16 and out.shape == (B, N, H, 64)
+    qr = qkv.detach().float().requires_grad_(True)
+    br = bias.detach().clone().requires_grad_(True)
+    q, k, v = qr.permute(2, 0, 3, 1, 4).unbind(0)
+    ref = ((((q @ k.transpose(-2, -1)) * scale) + br.unsqueeze(0)).softmax(-1) @ v).transpose(1, 2)
+    assert (out.float() - ref).abs().max().item() <= 3e-2 * max(1.0, ref.abs().max().item())
+    g = torch.randn_like(ref)
+    out.backward(g.to(torch.bfloat16))
+    ref.backward(g)
+    gerr = (qkv.grad.float() - qr.grad).abs().max().item()
+    assert gerr <= 6e-2 * max(1.0, qr.grad.abs().max().item()), gerr
+    berr = (bias.grad - br.grad).abs().max().item()
+    assert berr <= 2e-2 * max(1.0, br.grad.abs().max().item()), berr
+
+
+@pytest.mark.parametrize('B,hw,H', [(2, (4, 4), 2), (1, (14, 14), 3), (2, (40, 40), 2), (2, (5, 9), 1)])
+def test_attention_relative_position_table(B, hw, H):
+    """BEiT's form of the bias (base/beit.py:120-131): table (T, heads) indexed by relative_position_index (N, N) with the
+    class token's three extra rows.  Kernels build their operands from the table and reduce d(table) from dS: against the
+    fp32 expression, output / d(qkv) at the usual bf16 tolerances, d(table) within 2e-2 of its largest entry."""
+    from vitadapter import kernels
+    from vitadapter.backbones.beit import relative_position_index
+    torch.manual_seed(hw[0] * 7 + H)
+    index, T = relative_position_index(hw)
+    index = index.cuda()
+    N = hw[0] * hw[1] + 1
+    table = (torch.randn(T, H, device='cuda') * 1.5).requires_grad_(True)
+    qkv = (torch.randn(B, N, 3, H, 64, device='cuda') * 1.5).to(torch.bfloat16).requires_grad_(True)
+    scale = 64 ** -0.5
+    out = kernels.attention_relpos(qkv, table, index, scale)
+    assert out is not None and out.shape == (B, N, H, 64)
+    qr = qkv.detach().float().requires_grad_(True)
+    tr = table.detach().clone().requires_grad_(True)
+    bias = tr[index.view(-1)].view(N, N, H).permute(2, 0, 1)
+    q, k, v = qr.permute(2, 0, 3, 1, 4).unbind(0)
+    ref = ((((q @ k.transpose(-2, -1)) * scale) + bias.unsqueeze(0)).softmax(-1) @ v).transpose(1, 2)
+    assert (out.float() - ref).abs().max().item() <= 3e-2 * max(1.0, ref.abs().max().item())
+    g = torch.randn_like(ref)
+    out.backward(g.to(torch.bfloat16))
+    ref.backward(g)
+    assert (qkv.grad.float() - qr.grad).abs().max().item() <= 6e-2 * max(1.0, qr.grad.abs().max().item())
+    terr = (table.grad - tr.grad).abs().max().item()
+    assert terr <= 2e-2 * max(1.0, tr.grad.abs().max().item()), terr

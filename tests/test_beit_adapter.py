@@ -117,3 +117,54 @@ def test_hip_path_bf16_autocast_runs_and_tracks_fp32():
         outs = model(x.requires_grad_(True))
     sum(o.float().mean() for o in outs).backward()
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+@pytest.mark.gpu
+def test_hip_path_bf16_bias_attention_gradients_track_fp32():
+    """The relative position bias inside the MFMA attention kernels (csrc/attn_flash.hip, bf16 autocast) against the
+    fp32 run of the same model: gradients of every relative_position_bias_table (they leave the dQ pass as dS per
+    image, are summed over the batch and scattered back through the index) - relative L2 <= 0.15 each, median <= 0.08."""
+    import numpy as np
+    name = 'beit_seg_64'
+    model = _model(name, 'cuda').train()
+    for m in model.modules():                                      # deterministic graph for the two runs
+        if m.__class__.__name__ == 'DropPath':
+            m.drop_prob = 0.
+    x = bc.beit_input(name).cuda()
+    grads = {}
+    gouts = None
+    for amp in (False, True):
+        model.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.bfloat16, enabled=amp):
+            outs = model(x)
+        if gouts is None:
+            g = torch.Generator(device='cuda').manual_seed(3)
+            gouts = [torch.randn(o.shape, device='cuda', generator=g) for o in outs]
+        sum((o.float() * go).sum() for o, go in zip(outs, gouts)).backward()
+        grads[amp] = {k: p.grad.detach().double().clone() for k, p in model.named_parameters()
+                      if 'relative_position_bias_table' in k and p.grad is not None}
+    assert len(grads[True]) >= 2 and set(grads[True]) == set(grads[False])
+    rels = [float((grads[True][k] - grads[False][k]).norm() / grads[False][k].norm().clamp_min(1e-12)) for k in grads[False]]
+    assert max(rels) <= 0.15 and float(np.median(rels)) <= 0.08, rels
+
+
+@pytest.mark.gpu
+def test_beit_large_640_bf16_forward_backward():
+    """BASELINE configs[3] as published: BEiT-L adapter (embed 1024, depth 24, 16 heads, relative position bias, class
+    token, layer scale 1e-6, deform heads 16, ratio 0.5, with_cp) at 640 x 640, batch 2, train mode, bf16 autocast
+    (upernet_beit_adapter_large_640_160k_ade20k_ss.py:13-33): forward + backward through the bias attention kernels
+    (N = 1601 tokens), pyramid shapes, finite gradients for every parameter that has one."""
+    from vitadapter.backbones.beit_adapter import BEiTAdapter
+    torch.manual_seed(0)
+    model = BEiTAdapter(img_size=640, patch_size=16, embed_dim=1024, depth=24, num_heads=16, mlp_ratio=4, qkv_bias=True,
+                        use_abs_pos_emb=False, use_rel_pos_bias=True, init_values=1e-6, drop_path_rate=0.3, conv_inplane=64,
+                        n_points=4, deform_num_heads=16, cffn_ratio=0.25, deform_ratio=0.5, with_cp=True,
+                        interaction_indexes=[[0, 5], [6, 11], [12, 17], [18, 23]]).cuda().train()
+    x = torch.randn(2, 3, 640, 640, device='cuda', generator=torch.Generator(device='cuda').manual_seed(2))
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        outs = model(x)
+    assert [tuple(o.shape) for o in outs] == [(2, 1024, 160, 160), (2, 1024, 80, 80), (2, 1024, 40, 40), (2, 1024, 20, 20)]
+    sum(o.float().pow(2).mean() for o in outs).backward()
+    grads = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+    assert len(grads) > 500 and all(torch.isfinite(g).all() for g in grads.values())
+    assert sum('relative_position_bias_table' in k for k in grads) == 24

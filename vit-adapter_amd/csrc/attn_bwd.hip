@@ -365,7 +365,9 @@ static int attn_bwd_impl(const char *fn, const void *q, const void *k, const voi
     if (N >= (1 << 24)) return fail(VAH_E_SHAPE, "%s: N too large", fn);
     hipStream_t st = (hipStream_t)stream;
     // whole sequences: the lean kernels of attn_flash.hip (no transposed copies; of ws only B*H*N floats for delta)
-    if (rm.win == 0) return attn_bwd_seq(q, k, v, ld, out, dout, ld_out, lse, B, H, N, scale, (float *)ws, dq, dk, dv, ld_d, st);
+    if (rm.win == 0)
+        return attn_bwd_seq(q, k, v, ld, out, dout, ld_out, lse, B, H, N, scale, nullptr, nullptr, 0, nullptr, (float *)ws, dq, dk, dv,
+                            ld_d, st);
     const int Np = (int)((N + 63) / 64 * 64);
     const int64_t tsz = B * H * 64 * (int64_t)Np;
     __bf16 *kt = (__bf16 *)ws, *qt = kt + tsz, *dot = qt + tsz;
@@ -409,6 +411,28 @@ int vah_attn_bwd_bf16(const void *q, const void *k, const void *v, int64_t ld, i
         return fail(VAH_E_SHAPE, "%s: batch strides must be N*ld", fn);
     return attn_bwd_impl(fn, q, k, v, ld, attn::RowMap{0, 0, 0, 0, 0}, out, dout, ld_out, lse, B, H, N, scale, ws,
                          dq, dk, dv, ld_d, stream);
+}
+
+int vah_attn_bias_bwd_bf16(const void *q, const void *k, const void *v, int64_t ld, int64_t batch_stride, const void *out,
+                           const void *dout, int64_t ld_out, const float *lse, int64_t B, int64_t H, int64_t N, float scale,
+                           const void *bias, const void *bias_t, int64_t ldb, void *ds_out, float *delta_ws, void *dq, void *dk,
+                           void *dv, int64_t ld_d, int64_t batch_stride_d, void *stream) {
+    using namespace vah;
+    using namespace vah::attn;
+    clear_error();
+    const char *fn = "vah_attn_bias_bwd_bf16";
+    if (N > 0 && (batch_stride != N * ld || batch_stride_d != N * ld_d)) return fail(VAH_E_SHAPE, "%s: batch strides must be N*ld", fn);
+    if (B < 0 || H < 1 || N < 0 || ld < H * kHD || ld_out < H * kHD || ld_d < H * kHD || B > 65535 || H > 65535 || N >= (1 << 24) ||
+        ldb < N || ldb % 64)
+        return fail(VAH_E_SHAPE, "%s: bad dims (ldb must be a multiple of 64 >= N)", fn);
+    if (B == 0 || N == 0) return VAH_OK;
+    if (!q || !k || !v || !out || !dout || !lse || !bias || !bias_t || !ds_out || !delta_ws || !dq || !dk || !dv)
+        return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out | (uintptr_t)dout) % 16 || (ld % 8) || (ld_out % 8) || (ld_d % 4) ||
+        ((uintptr_t)dq | (uintptr_t)dk | (uintptr_t)dv | (uintptr_t)bias | (uintptr_t)bias_t | (uintptr_t)ds_out) % 8)
+        return fail(VAH_E_ALIGN, "%s: misaligned operand", fn);
+    return attn_bwd_seq(q, k, v, ld, out, dout, ld_out, lse, B, H, N, scale, bias, bias_t, ldb, ds_out, delta_ws, dq, dk, dv, ld_d,
+                        (hipStream_t)stream);
 }
 
 int vah_attn_win_bwd_bf16(const void *q, const void *k, const void *v, int64_t ld, const void *out,

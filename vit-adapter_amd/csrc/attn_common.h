@@ -82,13 +82,13 @@ __device__ __forceinline__ int64_t grow(const RowMap &rm, int z, int i, int N) {
 int make_rowmap(const char *fn, int64_t win, int64_t B, int64_t gh, int64_t gw, int64_t *Z, int64_t *N,
                 RowMap *rm);
 
-// attn_flash.hip: whole-sequence forward (rows b * N + i of a (B * N, ld) tensor)
+// attn_flash.hip: whole-sequence forward / backward (rows b * N + i of a (B * N, ld) tensor); bias (bf16, times
+// log2(e), (H, N, ldb)) and its transpose are optional, ds_out (B, H, N, ldb) receives d loss / d bias per image
 int attn_fwd_seq(const void *q, const void *k, const void *v, int64_t ld, int64_t B, int64_t H, int64_t N, float scale,
-                 void *out, int64_t ld_out, float *lse, hipStream_t st);
-
+                 const void *bias, int64_t ldb, void *out, int64_t ld_out, float *lse, hipStream_t st);
 int attn_bwd_seq(const void *q, const void *k, const void *v, int64_t ld, const void *o, const void *d_o, int64_t ld_out,
-                 const float *lse, int64_t B, int64_t H, int64_t N, float scale, float *delta, void *dq, void *dk, void *dv,
-                 int64_t ld_d, hipStream_t st);
+                 const float *lse, int64_t B, int64_t H, int64_t N, float scale, const void *bias, const void *bias_t,
+                 int64_t ldb, void *ds_out, float *delta, void *dq, void *dk, void *dv, int64_t ld_d, hipStream_t st);
 
 // attn_win.hip: forward with the whole window (N <= 224 tokens) resident in LDS, one workgroup per (window, head)
 int attn_win_fwd_resident(const void *q, const void *k, const void *v, int64_t ld, RowMap rm, int64_t Z, int64_t H,

@@ -54,9 +54,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kQB = 128, kKT = 64;
 
+// BIAS: an additive term per (head, query, key) - BEiT's relative position bias (base/beit.py:120-144): `bias` holds
+// bias * log2(e) as bf16, (H, N, ldb) with ldb a multiple of 64 >= N (columns beyond N unused)
+template <bool BIAS>
 __global__ __launch_bounds__(256) void attn_fwd_seq_kernel(
     const __bf16 *__restrict__ q, const __bf16 *__restrict__ k, const __bf16 *__restrict__ v, int64_t ld, int N, int H,
-    float scale_log2, __bf16 *__restrict__ out, int64_t ld_out, float *__restrict__ lse) {
+    float scale_log2, const __bf16 *__restrict__ bias, int64_t ldb, __bf16 *__restrict__ out, int64_t ld_out,
+    float *__restrict__ lse) {
     __shared__ __attribute__((aligned(16))) __bf16 s_k2[2][kKT * kPadRow];
     __shared__ __attribute__((aligned(16))) __bf16 s_v2[2][kKT * kPadRow];
     const int h = blockIdx.y, b = blockIdx.z;
@@ -107,6 +111,14 @@ __global__ __launch_bounds__(256) void attn_fwd_seq_kernel(
         }
         const __bf16 *s_k = s_k2[t & 1];
         const __bf16 *vbase = tile_lane_base(s_v2[t & 1], lane);
+        bf16x4 bv[2][4];
+        if constexpr (BIAS) {           // this lane's query row, 4 consecutive keys per register group
+            const __bf16 *bp = bias + ((int64_t)h * N + min(qrow, N - 1)) * ldb + t * kKT + 4 * hf;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bv[kb][g] = *reinterpret_cast<const bf16x4 *>(bp + 32 * kb + 8 * g);
+        }
 
         f32x16 s[2];
 #pragma unroll
@@ -115,6 +127,16 @@ __global__ __launch_bounds__(256) void attn_fwd_seq_kernel(
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
                 s[kb] = mfma(*reinterpret_cast<const bf16x8 *>(s_k + (kb * 32 + r) * kPadRow + 16 * kk + 8 * hf), qf[kk], s[kb]);
+        }
+        if constexpr (BIAS) {           // scores in the log2 domain from here on
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) {
+                    const f32x2 x = f32x2{s[kb][i], s[kb][i + 1]} * sc2 + f32x2{(float)bv[kb][i >> 2][i & 3], (float)bv[kb][i >> 2][(i & 3) + 1]};
+                    s[kb][i] = x[0];
+                    s[kb][i + 1] = x[1];
+                }
         }
         if (t == ntiles - 1) {
             const int key0 = t * kKT;
@@ -132,7 +154,7 @@ __global__ __launch_bounds__(256) void attn_fwd_seq_kernel(
             mq[c] = fmaxf(mq[c], fmaxf(fmaxf(s[1][4 * c], s[1][4 * c + 1]), fmaxf(s[1][4 * c + 2], s[1][4 * c + 3])));
         }
         const float mx = max_halves(fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3])));
-        const float m_new = fmaxf(m_run, mx * scale_log2);
+        const float m_new = fmaxf(m_run, BIAS ? mx : mx * scale_log2);
         if (__builtin_amdgcn_ballot_w64(m_new > m_run)) {                // some row's maximum moved: rescale
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);    // first tile: exp2(-inf) = 0
             lsum[0] *= alpha;                                             // every row of lsum is the same sum: row 0 is read
@@ -148,7 +170,8 @@ __global__ __launch_bounds__(256) void attn_fwd_seq_kernel(
 #pragma unroll
             for (int i = 0; i < 16; i += 2) {
                 f32x2 x = {s[kb][i], s[kb][i + 1]};
-                x = x * sc2 - f32x2{m_run, m_run};
+                if constexpr (BIAS) x = x - f32x2{m_run, m_run};
+                else x = x * sc2 - f32x2{m_run, m_run};
                 s[kb][i] = __builtin_amdgcn_exp2f(x[0]);
                 s[kb][i + 1] = __builtin_amdgcn_exp2f(x[1]);
             }
@@ -191,10 +214,14 @@ __global__ __launch_bounds__(256) void attn_fwd_seq_kernel(
 // own queries and handed to the dK/dV kernel through `delta`; no window arithmetic in the loops; staged rows beyond N
 // are clamped, not zero-filled.
 // ---------------------------------------------------------------------------------------
+// BIAS: scores carry `bias` as in the forward; dS (= d loss / d bias of this image) is written to ds_out
+// (B, H, N, ldb) bf16, the caller sums it over the batch
+template <bool BIAS>
 __global__ __launch_bounds__(256) void attn_bwd_dq_seq_kernel(
     const __bf16 *__restrict__ q, const __bf16 *__restrict__ k, const __bf16 *__restrict__ v, int64_t ld,
     const __bf16 *__restrict__ o, const __bf16 *__restrict__ d_o, int64_t ld_out, const float *__restrict__ lse, int N, int H,
-    float scale, float scale_log2, float *__restrict__ delta, __bf16 *__restrict__ dq, int64_t ld_d) {
+    float scale, float scale_log2, const __bf16 *__restrict__ bias, int64_t ldb, __bf16 *__restrict__ ds_out,
+    float *__restrict__ delta, __bf16 *__restrict__ dq, int64_t ld_d) {
     __shared__ __attribute__((aligned(16))) __bf16 s_k2[2][kKT * kPadRow];
     __shared__ __attribute__((aligned(16))) __bf16 s_v2[2][kKT * kPadRow];
     const int h = blockIdx.y, b = blockIdx.z;
@@ -249,6 +276,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_seq_kernel(
         }
         const __bf16 *s_k = s_k2[t & 1], *s_v = s_v2[t & 1];
         const __bf16 *kbase = tile_lane_base(s_k, lane);
+        bf16x4 bv[2][4];
+        const int64_t brow = ((int64_t)h * N + min(qrow, N - 1)) * ldb + t * kKT + 4 * hf;
+        if constexpr (BIAS) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bv[kb][g] = *reinterpret_cast<const bf16x4 *>(bias + brow + 32 * kb + 8 * g);
+        }
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             f32x16 s = zero16(), dp = zero16();
@@ -259,7 +294,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_seq_kernel(
             }
 #pragma unroll
             for (int i = 0; i < 16; i += 2) {                           // dS^T = P^T o (dP^T - delta)
-                const f32x2 x = f32x2{s[i], s[i + 1]} * sc2 - ls2;
+                f32x2 x = f32x2{s[i], s[i + 1]} * sc2 - ls2;
+                if constexpr (BIAS) x = x + f32x2{(float)bv[kb][i >> 2][i & 3], (float)bv[kb][i >> 2][(i & 3) + 1]};
                 const f32x2 pr = {__builtin_amdgcn_exp2f(x[0]), __builtin_amdgcn_exp2f(x[1])};
                 const f32x2 ds = pr * (f32x2{dp[i], dp[i + 1]} - de2);
                 s[i] = ds[0];
@@ -269,6 +305,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_seq_kernel(
 #pragma unroll
                 for (int i = 0; i < 16; ++i)
                     if (t * kKT + kb * 32 + crow(i, hf) >= N) s[i] = 0.f;
+            }
+            if constexpr (BIAS) {
+                if (qrow < N) {
+                    __bf16 *dp_ = ds_out + (int64_t)b * H * N * ldb + brow + 32 * kb;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        bf16x4 w;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) w[j] = (__bf16)s[4 * g + j];
+                        *reinterpret_cast<bf16x4 *>(dp_ + 8 * g) = w;
+                    }
+                }
             }
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
@@ -293,10 +341,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_seq_kernel(
 }
 
 // dK, dV: workgroup = 128 keys (32 per wave), loop over query tiles of 64
+// BIAS: bias_t = the forward's bias TRANSPOSED, (H, N keys, ldb queries): this lane's key row, 4 consecutive queries
+template <bool BIAS>
 __global__ __launch_bounds__(256) void attn_bwd_dkdv_seq_kernel(
     const __bf16 *__restrict__ q, const __bf16 *__restrict__ k, const __bf16 *__restrict__ v, int64_t ld,
     const __bf16 *__restrict__ d_o, int64_t ld_out, const float *__restrict__ lse, const float *__restrict__ delta, int N, int H,
-    float scale, float scale_log2, __bf16 *__restrict__ dk, __bf16 *__restrict__ dv, int64_t ld_d) {
+    float scale, float scale_log2, const __bf16 *__restrict__ bias_t, int64_t ldb, __bf16 *__restrict__ dk,
+    __bf16 *__restrict__ dv, int64_t ld_d) {
     __shared__ __attribute__((aligned(16))) __bf16 s_q2[2][kKT * kPadRow];
     __shared__ __attribute__((aligned(16))) __bf16 s_do2[2][kKT * kPadRow];
     __shared__ __attribute__((aligned(16))) float s_lse2[2][kKT];
@@ -357,6 +408,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_seq_kernel(
         const __bf16 *s_q = s_q2[t & 1], *s_do = s_do2[t & 1];
         const float *s_lse = s_lse2[t & 1], *s_delta = s_delta2[t & 1];
         const __bf16 *qbase = tile_lane_base(s_q, lane), *dobase = tile_lane_base(s_do, lane);
+        bf16x4 bv[2][4];
+        if constexpr (BIAS) {
+            const __bf16 *bp = bias_t + ((int64_t)h * N + min(krow, N - 1)) * ldb + t * kKT + 4 * hf;
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bv[qb][g] = *reinterpret_cast<const bf16x4 *>(bp + 32 * qb + 8 * g);
+        }
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
             f32x16 s = zero16(), dp = zero16();
@@ -370,7 +429,11 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_seq_kernel(
                 const float4 l4 = *reinterpret_cast<const float4 *>(s_lse + qb * 32 + 8 * g + 4 * hf);
                 const float4 d4 = *reinterpret_cast<const float4 *>(s_delta + qb * 32 + 8 * g + 4 * hf);
                 const f32x2 l01 = {l4.x, l4.y}, l23 = {l4.z, l4.w}, d01 = {d4.x, d4.y}, d23 = {d4.z, d4.w};
-                const f32x2 x0 = f32x2{s[4 * g], s[4 * g + 1]} * sc2 - l01, x1 = f32x2{s[4 * g + 2], s[4 * g + 3]} * sc2 - l23;
+                f32x2 x0 = f32x2{s[4 * g], s[4 * g + 1]} * sc2 - l01, x1 = f32x2{s[4 * g + 2], s[4 * g + 3]} * sc2 - l23;
+                if constexpr (BIAS) {
+                    x0 = x0 + f32x2{(float)bv[qb][g][0], (float)bv[qb][g][1]};
+                    x1 = x1 + f32x2{(float)bv[qb][g][2], (float)bv[qb][g][3]};
+                }
                 const f32x2 p0 = {__builtin_amdgcn_exp2f(x0[0]), __builtin_amdgcn_exp2f(x0[1])};
                 const f32x2 p1 = {__builtin_amdgcn_exp2f(x1[0]), __builtin_amdgcn_exp2f(x1[1])};
                 const f32x2 e0 = p0 * (f32x2{dp[4 * g], dp[4 * g + 1]} - d01), e1 = p1 * (f32x2{dp[4 * g + 2], dp[4 * g + 3]} - d23);
@@ -409,32 +472,47 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_seq_kernel(
 }  // namespace
 
 int attn_fwd_seq(const void *q, const void *k, const void *v, int64_t ld, int64_t B, int64_t H, int64_t N, float scale,
-                 void *out, int64_t ld_out, float *lse, hipStream_t st) {
-    hipLaunchKernelGGL(attn_fwd_seq_kernel, dim3((unsigned)((N + kQB - 1) / kQB), (unsigned)H, (unsigned)B), dim3(256), 0, st,
-                       (const __bf16 *)q, (const __bf16 *)k, (const __bf16 *)v, ld, (int)N, (int)H,
-                       scale * 1.4426950408889634f, (__bf16 *)out, ld_out, lse);
+                 const void *bias, int64_t ldb, void *out, int64_t ld_out, float *lse, hipStream_t st) {
+    const dim3 grid((unsigned)((N + kQB - 1) / kQB), (unsigned)H, (unsigned)B);
+    if (bias)
+        hipLaunchKernelGGL(attn_fwd_seq_kernel<true>, grid, dim3(256), 0, st, (const __bf16 *)q, (const __bf16 *)k,
+                           (const __bf16 *)v, ld, (int)N, (int)H, scale * 1.4426950408889634f, (const __bf16 *)bias, ldb,
+                           (__bf16 *)out, ld_out, lse);
+    else
+        hipLaunchKernelGGL(attn_fwd_seq_kernel<false>, grid, dim3(256), 0, st, (const __bf16 *)q, (const __bf16 *)k,
+                           (const __bf16 *)v, ld, (int)N, (int)H, scale * 1.4426950408889634f, (const __bf16 *)nullptr,
+                           (int64_t)0, (__bf16 *)out, ld_out, lse);
     return check_launch("attn_fwd_seq");
 }
 
-
 int attn_bwd_seq(const void *q, const void *k, const void *v, int64_t ld, const void *o, const void *d_o, int64_t ld_out,
-                 const float *lse, int64_t B, int64_t H, int64_t N, float scale, float *delta, void *dq, void *dk, void *dv,
-                 int64_t ld_d, hipStream_t st) {
+                 const float *lse, int64_t B, int64_t H, int64_t N, float scale, const void *bias, const void *bias_t,
+                 int64_t ldb, void *ds_out, float *delta, void *dq, void *dk, void *dv, int64_t ld_d, hipStream_t st) {
     const dim3 grid((unsigned)((N + kQB - 1) / kQB), (unsigned)H, (unsigned)B);
     const float scale_log2 = scale * 1.4426950408889634f;
     {
         // useful flops of the whole backward = 2.5x the forward (S, dP, dV, dK, dQ products); both kernels form S and
         // dP: dq runs 3 products (6 B H N^2 64), dkdv 4 (8 B H N^2 64)
         LaunchScope scope("attn_bwd_dq_bf16", 6 * B * H * N * kHD * 2, st, 0, 6 * B * H * N * N * kHD);
-        hipLaunchKernelGGL(attn_bwd_dq_seq_kernel, grid, dim3(256), 0, st, (const __bf16 *)q, (const __bf16 *)k,
-                           (const __bf16 *)v, ld, (const __bf16 *)o, (const __bf16 *)d_o, ld_out, lse, (int)N, (int)H, scale,
-                           scale_log2, delta, (__bf16 *)dq, ld_d);
+        if (bias)
+            hipLaunchKernelGGL(attn_bwd_dq_seq_kernel<true>, grid, dim3(256), 0, st, (const __bf16 *)q, (const __bf16 *)k,
+                               (const __bf16 *)v, ld, (const __bf16 *)o, (const __bf16 *)d_o, ld_out, lse, (int)N, (int)H, scale,
+                               scale_log2, (const __bf16 *)bias, ldb, (__bf16 *)ds_out, delta, (__bf16 *)dq, ld_d);
+        else
+            hipLaunchKernelGGL(attn_bwd_dq_seq_kernel<false>, grid, dim3(256), 0, st, (const __bf16 *)q, (const __bf16 *)k,
+                               (const __bf16 *)v, ld, (const __bf16 *)o, (const __bf16 *)d_o, ld_out, lse, (int)N, (int)H, scale,
+                               scale_log2, (const __bf16 *)nullptr, (int64_t)0, (__bf16 *)nullptr, delta, (__bf16 *)dq, ld_d);
         if (int rc = check_launch("attn_bwd_dq_seq")) return rc;
     }
     LaunchScope scope("attn_bwd_dkdv_bf16", 8 * B * H * N * kHD * 2, st, 0, 8 * B * H * N * N * kHD);
-    hipLaunchKernelGGL(attn_bwd_dkdv_seq_kernel, grid, dim3(256), 0, st, (const __bf16 *)q, (const __bf16 *)k,
-                       (const __bf16 *)v, ld, (const __bf16 *)d_o, ld_out, lse, delta, (int)N, (int)H, scale, scale_log2,
-                       (__bf16 *)dk, (__bf16 *)dv, ld_d);
+    if (bias)
+        hipLaunchKernelGGL(attn_bwd_dkdv_seq_kernel<true>, grid, dim3(256), 0, st, (const __bf16 *)q, (const __bf16 *)k,
+                           (const __bf16 *)v, ld, (const __bf16 *)d_o, ld_out, lse, delta, (int)N, (int)H, scale, scale_log2,
+                           (const __bf16 *)bias_t, ldb, (__bf16 *)dk, (__bf16 *)dv, ld_d);
+    else
+        hipLaunchKernelGGL(attn_bwd_dkdv_seq_kernel<false>, grid, dim3(256), 0, st, (const __bf16 *)q, (const __bf16 *)k,
+                           (const __bf16 *)v, ld, (const __bf16 *)d_o, ld_out, lse, delta, (int)N, (int)H, scale, scale_log2,
+                           (const __bf16 *)nullptr, (int64_t)0, (__bf16 *)dk, (__bf16 *)dv, ld_d);
     return check_launch("attn_bwd_dkdv_seq");
 }
 

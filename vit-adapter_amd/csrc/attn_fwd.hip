@@ -217,6 +217,26 @@ int vah_attn_fwd_bf16(const void *q, const void *k, const void *v, int64_t ld, i
     return attn_fwd_impl(fn, q, k, v, ld, attn::RowMap{0, 0, 0, 0, 0}, B, H, N, scale, vt_ws, out, ld_out, lse, stream);
 }
 
+int vah_attn_bias_fwd_bf16(const void *q, const void *k, const void *v, int64_t ld, int64_t batch_stride, int64_t B, int64_t H,
+                           int64_t N, float scale, const void *bias, int64_t ldb, void *out, int64_t ld_out, float *lse,
+                           void *stream) {
+    using namespace vah;
+    using namespace vah::attn;
+    clear_error();
+    const char *fn = "vah_attn_bias_fwd_bf16";
+    if (N > 0 && batch_stride != N * ld) return fail(VAH_E_SHAPE, "%s: batch_stride must be N*ld", fn);
+    if (B < 0 || H < 1 || N < 0 || ld < H * kHD || ld_out < H * kHD || B > 65535 || H > 65535 || N >= (1 << 24) || ldb < N ||
+        ldb % 64)
+        return fail(VAH_E_SHAPE, "%s: bad dims (ldb must be a multiple of 64 >= N)", fn);
+    if (B == 0 || N == 0) return VAH_OK;
+    if (!q || !k || !v || !bias || !out || !lse) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 || (ld % 8) || ((uintptr_t)out | (uintptr_t)bias) % 8 || (ld_out % 4))
+        return fail(VAH_E_ALIGN, "%s: q/k/v need 16-byte aligned rows (ld %% 8 == 0), out / bias 8-byte", fn);
+    hipStream_t st = (hipStream_t)stream;
+    LaunchScope scope("attn_bias_fwd_bf16", 4 * B * H * N * kHD * 2 + B * H * N * 4 + B * H * N * N * 2, st, 0, 4 * B * H * N * N * kHD);
+    return attn_fwd_seq(q, k, v, ld, B, H, N, scale, bias, ldb, out, ld_out, lse, st);
+}
+
 int vah_attn_win_fwd_bf16(const void *q, const void *k, const void *v, int64_t ld, int64_t B,
                           int64_t grid_h, int64_t grid_w, int64_t win, int64_t H, float scale,
                           void *vt_ws, void *out, int64_t ld_out, float *lse, void *stream) {
@@ -257,7 +277,7 @@ static int attn_fwd_impl(const char *fn, const void *q, const void *k, const voi
     if (rm.win == 0) {
         // whole sequences: the lean kernel of attn_flash.hip (no V^T workspace, no transpose launch)
         LaunchScope scope("attn_fwd_bf16", 4 * B * H * N * kHD * 2 + B * H * N * 4, st, 0, 4 * B * H * N * N * kHD);
-        return attn_fwd_seq(q, k, v, ld, B, H, N, scale, out, ld_out, lse, st);
+        return attn_fwd_seq(q, k, v, ld, B, H, N, scale, nullptr, 0, out, ld_out, lse, st);
     }
     const int Np = (int)vah_attn_padded_len(N);
     {

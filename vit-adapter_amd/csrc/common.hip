@@ -103,7 +103,7 @@ LaunchScope::~LaunchScope() {
 
 extern "C" {
 
-int vah_abi_version(void) { return 29; }
+int vah_abi_version(void) { return 31; }
 
 const char *vah_last_error(void) { return vah::g_err; }
 

@@ -21,7 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as cp
 
-from .. import fused
+from .. import fused, kernels
 from .vit import DropPath, to_2tuple
 
 
@@ -98,11 +98,26 @@ class Attention(nn.Module):
         qkv_bias = None
         if self.q_bias is not None:
             qkv_bias = torch.cat((self.q_bias, torch.zeros_like(self.v_bias, requires_grad=False), self.v_bias))
-        qkv = F.linear(x, self.qkv.weight, qkv_bias).reshape(B, N, 3, self.num_heads, -1).permute(2, 0, 3, 1, 4)
+        packed = F.linear(x, self.qkv.weight, qkv_bias).reshape(B, N, 3, self.num_heads, -1)
+        drop = self.attn_drop.p if self.training else 0.
+        fast = x.is_cuda and packed.dtype == torch.bfloat16 and drop == 0.
+        out = None
+        if (fast and rel_pos_bias is None and self.relative_position_bias_table is not None
+                and N == self.window_size[0] * self.window_size[1] + 1):
+            # bf16 autocast: the MFMA kernels of csrc/attn_flash.hip with the relative position bias as an additive term
+            # inside them, its two bf16 operands built straight from the table (no (heads, N, N) fp32 tensor)
+            out = kernels.attention_relpos(packed, self.relative_position_bias_table, self.relative_position_index, self.scale)
+        bias = None
+        if out is None:
+            bias = self.bias()
+            if rel_pos_bias is not None:
+                bias = rel_pos_bias if bias is None else bias + rel_pos_bias
+            if fast:
+                out = kernels.attention_bias(packed, bias, self.scale) if bias is not None else kernels.attention(packed, self.scale)
+        if out is not None:
+            return self.proj_drop(fused.linear(self.proj, out.reshape(B, N, -1)))
+        qkv = packed.permute(2, 0, 3, 1, 4)
         q, k, v = qkv[0], qkv[1], qkv[2]
-        bias = self.bias()
-        if rel_pos_bias is not None:
-            bias = rel_pos_bias if bias is None else bias + rel_pos_bias
         if x.is_cuda:
             mask = bias.unsqueeze(0).to(q.dtype) if bias is not None else None
             out = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, scale=self.scale,

@@ -199,12 +199,22 @@ PRESETS = {
                       deform_num_heads=16, cffn_ratio=0.25, deform_ratio=0.5, with_cp=True,
                       interaction_indexes=[[0, 5], [6, 11], [12, 17], [18, 23]],
                       window_attn=[False] * 24, window_size=[None] * 24),
+    # seg/configs/ade20k/upernet_beit_adapter_large_640_160k_ade20k_ss.py:13-33 (BASELINE configs[3] as published):
+    # built by BEiTAdapter (class token, relative position bias, layer scale), see build_preset
+    'beit_large_seg': dict(flavour='seg', beit=True, img_size=640, patch_size=16, embed_dim=1024, depth=24, num_heads=16,
+                           mlp_ratio=4, qkv_bias=True, use_abs_pos_emb=False, use_rel_pos_bias=True, init_values=1e-6,
+                           drop_path_rate=0.3, conv_inplane=64, n_points=4, deform_num_heads=16, cffn_ratio=0.25,
+                           deform_ratio=0.5, with_cp=True, interaction_indexes=[[0, 5], [6, 11], [12, 17], [18, 23]]),
 }
 
 
 def build_preset(name, **overrides):
     kw = dict(PRESETS[name])
     kw.update(overrides)
+    if kw.pop('beit', False):
+        from .beit_adapter import BEiTAdapter
+        kw.pop('flavour', None)
+        return BEiTAdapter(**kw)
     return ViTAdapter(**kw)
 
 
