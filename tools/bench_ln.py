@@ -17,6 +17,8 @@ def main():
     C = 768
     norm = torch.nn.LayerNorm(C, eps=1e-6).cuda()
     gamma = torch.ones(C, device='cuda', requires_grad=True)
+    import _vah
+    _vah.prof_enable(True, 'layernorm,residual_layernorm')
     for rows in (8192, 43008):
         x = torch.randn(2, rows // 2, C, device='cuda', requires_grad=True)
         z = torch.randn(2, rows // 2, C, device='cuda').to(torch.bfloat16).requires_grad_(True)
@@ -33,6 +35,9 @@ def main():
             tf = timeit(lambda: fused.layer_norm(norm, x), iters=30)
         g2 = torch.randn_like(y2)
         tb = timeit(lambda: torch.autograd.grad(y2, [x, norm.weight, norm.bias], g2, retain_graph=True), iters=30)
+        rep = _vah.prof_report()
+        _vah.prof_enable(True, 'layernorm,residual_layernorm')
+        print('   GPU time per launch: ' + ', '.join('%s %.1f us' % (k, v['total_ms'] / v['calls'] * 1e3) for k, v in sorted(rep.items())))
         print('rows %6d LN          fwd %6.1f us (%.2f TB/s on %d MB) | bwd %6.1f us (%.2f TB/s on %d MB)'
               % (rows, tf * 1e6, n * 6 / tf / 1e12, n * 6 >> 20, tb * 1e6, n * 10 / tb / 1e12, n * 10 >> 20), flush=True)
 

@@ -103,7 +103,7 @@ class MSDeformAttnFusedFunction(Function):
         win = window_schedule_for(reference_points, spatial_shapes, level_start_index, value.dtype) \
             if (L == 1 and P == 4 and ref.shape[1] == 1) else None
         if win is not None:
-            with torch.cuda.device(value.device):
+            with _vah.on(value.device):
                 rc = _vah.lib.vah_msda_fused_forward_win(
                     value.data_ptr(), _DT[value.dtype], offsets.data_ptr(), logits.data_ptr(), _DT[offsets.dtype],
                     ref.data_ptr(), win.perm.data_ptr(), win.group_off.data_ptr(), win.group_win.data_ptr(),
@@ -113,7 +113,7 @@ class MSDeformAttnFusedFunction(Function):
             ctx.save_for_backward(value, spatial_shapes, level_start_index, offsets, logits, ref)
             ctx.tiled = tiled_backward(L, P)
             return out
-        with torch.cuda.device(value.device):
+        with _vah.on(value.device):
             rc = _vah.lib.vah_msda_fused_forward(
                 value.data_ptr(), _DT[value.dtype], spatial_shapes.data_ptr(),
                 level_start_index.data_ptr(), offsets.data_ptr(), logits.data_ptr(),
@@ -140,7 +140,7 @@ class MSDeformAttnFusedFunction(Function):
             if ws_bytes >= 0:
                 grad_value = torch.empty_like(value)
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
-                with torch.cuda.device(value.device):
+                with _vah.on(value.device):
                     rc = _vah.lib.vah_msda_fused_backward_tiled(
                         value.data_ptr(), _DT[value.dtype], shapes.data_ptr(), lsi.data_ptr(),
                         offsets.data_ptr(), logits.data_ptr(), _DT[offsets.dtype], ref.data_ptr(),
@@ -151,7 +151,7 @@ class MSDeformAttnFusedFunction(Function):
                 return grad_value, None, None, d_off, d_logit, None
         # fallback: one float atomic per sample, corner and channel into a zeroed fp32 grad_value
         grad_value = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
-        with torch.cuda.device(value.device):
+        with _vah.on(value.device):
             rc = _vah.lib.vah_msda_fused_backward(
                 value.data_ptr(), _DT[value.dtype], shapes.data_ptr(), lsi.data_ptr(),
                 offsets.data_ptr(), logits.data_ptr(), _DT[offsets.dtype], ref.data_ptr(),

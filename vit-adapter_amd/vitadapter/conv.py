@@ -20,7 +20,7 @@ def _taps(call, x, w, taps, S, out, ny, nx, OS, oy0, ox0):
     Cout, T = w.shape[0], len(taps)
     ty = (ctypes.c_int * T)(*[t[0] for t in taps])
     tx = (ctypes.c_int * T)(*[t[1] for t in taps])
-    with torch.cuda.device(x.device):
+    with _vah.on(x.device):
         rc = _vah.lib.vah_conv_taps_nhwc_bf16(x.data_ptr(), N, IH, IW, Cin, w.data_ptr(), Cout, T, ty, tx, S, out.data_ptr(), ny,
                                               nx, out.shape[1], out.shape[2], OS, oy0, ox0, _stream(x))
     _vah.check(rc, call)
@@ -51,7 +51,7 @@ def conv3x3_input_grad(gy, wt9, stride, in_hw):
     N, OH, OW, cout = gy.shape
     cin = wt9.shape[0]
     gx = torch.empty((N, H, W, cin), dtype=torch.bfloat16, device=gy.device)
-    with torch.cuda.device(gy.device):
+    with _vah.on(gy.device):
         rc = _vah.lib.vah_conv3x3_dgrad_nhwc_bf16(gy.data_ptr(), N, OH, OW, cout, wt9.data_ptr(), cin, stride, gx.data_ptr(), H, W,
                                                   _stream(gy))
     _vah.check(rc, 'vah_conv3x3_dgrad_nhwc_bf16')
@@ -65,7 +65,7 @@ def conv3x3_weight_grad(x, gy, stride):
     nws = _vah.lib.vah_conv3x3_wgrad_ws_floats(cin, cout)
     ws = torch.empty((nws,), dtype=torch.float32, device=x.device)
     dw = torch.empty((cout, 3, 3, cin), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _vah.on(x.device):
         rc = _vah.lib.vah_conv3x3_wgrad_nhwc_bf16(x.data_ptr(), N, H, W, cin, gy.data_ptr(), OH, OW, cout, stride, ws.data_ptr(),
                                                   nws, dw.data_ptr(), _stream(x))
     _vah.check(rc, 'vah_conv3x3_wgrad_nhwc_bf16')

@@ -49,7 +49,7 @@ class _LayerNormBF16(torch.autograd.Function):
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         w, b = weight.contiguous(), bias.contiguous()
-        with torch.cuda.device(x.device):
+        with _vah.on(x.device):
             _vah.check(_vah.lib.vah_layernorm_fwd_f32_bf16(
                 x2.data_ptr(), w.data_ptr(), b.data_ptr(), rows, C, float(eps), y.data_ptr(),
                 mean.data_ptr(), rstd.data_ptr(), _stream(x)), 'layernorm_fwd')
@@ -73,7 +73,7 @@ class _LayerNormBF16(torch.autograd.Function):
         dx = torch.empty_like(x2)
         dwb = torch.empty(2, C, dtype=torch.float32, device=x2.device)
         ws = _scratch(2 * C, x2.device)
-        with torch.cuda.device(x2.device):
+        with _vah.on(x2.device):
             _vah.check(_vah.lib.vah_layernorm_bwd_f32_bf16(
                 x2.data_ptr(), g.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                 gres.data_ptr() if gres is not None else None, rows, C,
@@ -104,7 +104,7 @@ class _LayerNormDualBF16(torch.autograd.Function):
         mean = torch.empty(rows, dtype=torch.float32, device=x.device)
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         wa, ba, wb, bb = (t.contiguous() for t in (wa, ba, wb, bb))
-        with torch.cuda.device(x.device):
+        with _vah.on(x.device):
             _vah.check(_vah.lib.vah_layernorm_dual_fwd(
                 x2.data_ptr(), wa.data_ptr(), ba.data_ptr(), wb.data_ptr(), bb.data_ptr(), rows, C, float(eps),
                 ya.data_ptr(), yb.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream(x)), 'layernorm_dual_fwd')
@@ -126,7 +126,7 @@ class _LayerNormDualBF16(torch.autograd.Function):
         dx = torch.empty_like(x2)
         dp = torch.empty(4, C, dtype=torch.float32, device=x2.device)
         ws = _scratch(2 * C, x2.device)
-        with torch.cuda.device(x2.device):
+        with _vah.on(x2.device):
             _vah.check(_vah.lib.vah_layernorm_dual_bwd(
                 x2.data_ptr(), ga.data_ptr() if ga is not None else None, gb.data_ptr() if gb is not None else None,
                 wa.data_ptr(), wb.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
@@ -300,7 +300,7 @@ def gemm_bf16(a, b, trans_a=False, trans_b=False, out_dtype=torch.bfloat16, bias
         ws_bytes += min(64 * M * N * 4, 160 << 20)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=a.device)
     epilogue = _vah.GEMM_EPI_BIAS if bias is not None else _vah.GEMM_EPI_NONE
-    with torch.cuda.device(a.device):
+    with _vah.on(a.device):
         _vah.check(_vah.lib.vah_gemm_bf16(
             int(trans_a), int(trans_b), M, N, K, a.data_ptr(), a.shape[1], b.data_ptr(), b.shape[1],
             d.data_ptr(), N, int(out_dtype == torch.float32), epilogue,
@@ -324,7 +324,7 @@ def _wgrad_bgrad(g2, x2):
     ws_bytes = _GEMM_WS_BYTES + (min(64 * N * K * 4, 160 << 20) if R >= 4096 else 0)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     nparts = ctypes.c_int64(0)
-    with torch.cuda.device(dev):
+    with _vah.on(dev):
         st = _stream(g2)
         _vah.check(_vah.lib.vah_colsum_bf16_partials(g2.data_ptr(), R, N, cws.data_ptr(), ctypes.byref(nparts), st),
                    'colsum_partials')
@@ -379,7 +379,7 @@ class _LinearBF16(torch.autograd.Function):
             if want_b:
                 gb = torch.empty(N, dtype=torch.float32, device=g2.device)
                 ws = _scratch(N, g2.device)
-                with torch.cuda.device(g2.device):
+                with _vah.on(g2.device):
                     _vah.check(_vah.lib.vah_colsum_bf16(g2.data_ptr(), g2.shape[0], N, gb.data_ptr(),
                                                         ws.data_ptr(), _stream(g2)), 'colsum')
         return gx, gw, gb
@@ -457,7 +457,7 @@ class _LinearPairBF16(torch.autograd.Function):
             if want_b:
                 gbias = torch.empty(na + nb, dtype=torch.float32, device=g.device)
                 ws = _scratch(na + nb, g.device)
-                with torch.cuda.device(g.device):
+                with _vah.on(g.device):
                     _vah.check(_vah.lib.vah_colsum_bf16(g.data_ptr(), R, na + nb, gbias.data_ptr(), ws.data_ptr(),
                                                         _stream(g)), 'colsum')
         return (gx, gw[:na] if gw is not None else None, gbias[:na] if gbias is not None else None,
@@ -543,7 +543,7 @@ class _ScaleResidual(torch.autograd.Function):
         x, z = x.contiguous(), z.contiguous()
         y = torch.empty_like(x)
         gp = gamma.contiguous() if gamma is not None else None
-        with torch.cuda.device(x.device):
+        with _vah.on(x.device):
             _vah.check(_vah.lib.vah_scale_residual_fwd(
                 x.data_ptr(), z.data_ptr(), gp.data_ptr() if gp is not None else None,
                 s.data_ptr() if s is not None else None, B, rpb, C, y.data_ptr(), _stream(x)),
@@ -560,7 +560,7 @@ class _ScaleResidual(torch.autograd.Function):
         dz = torch.empty_like(z)
         dgamma = torch.empty(C, dtype=torch.float32, device=g.device) if gp is not None else None
         ws = _scratch(C, g.device) if gp is not None else None
-        with torch.cuda.device(g.device):
+        with _vah.on(g.device):
             _vah.check(_vah.lib.vah_scale_residual_bwd(
                 g.data_ptr(), z.data_ptr(), gp.data_ptr() if gp is not None else None,
                 s.data_ptr() if s is not None else None, B, rpb, C, dz.data_ptr(),
@@ -602,7 +602,7 @@ class _ResidualLN(torch.autograd.Function):
         rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
         gp = gamma.contiguous() if gamma is not None else None
         w, b = weight.contiguous(), bias.contiguous()
-        with torch.cuda.device(x.device):
+        with _vah.on(x.device):
             _vah.check(_vah.lib.vah_residual_layernorm_fwd(
                 x.data_ptr(), z.data_ptr(), gp.data_ptr() if gp is not None else None,
                 s.data_ptr() if s is not None else None, B, rpb, C, w.data_ptr(), b.data_ptr(), float(eps),
@@ -625,7 +625,7 @@ class _ResidualLN(torch.autograd.Function):
             dz = torch.empty_like(z)
             dgamma = torch.empty(C, dtype=torch.float32, device=dev) if gp is not None else None
             ws = _scratch(C, dev) if gp is not None else None
-            with torch.cuda.device(dev):
+            with _vah.on(dev):
                 _vah.check(_vah.lib.vah_scale_residual_bwd(
                     gt.data_ptr(), z.data_ptr(), gp.data_ptr() if gp is not None else None,
                     s.data_ptr() if s is not None else None, B, rpb, C, dz.data_ptr(),
@@ -637,7 +637,7 @@ class _ResidualLN(torch.autograd.Function):
         dz = torch.empty_like(z)
         grads = torch.empty(3, C, dtype=torch.float32, device=dev)
         ws = _scratch(3 * C, dev)
-        with torch.cuda.device(dev):
+        with _vah.on(dev):
             _vah.check(_vah.lib.vah_residual_layernorm_bwd(
                 t.data_ptr(), gh.data_ptr(), w.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
                 gt.data_ptr() if gt is not None else None, z.data_ptr(),
@@ -673,7 +673,7 @@ class _DWConvTokens(torch.autograd.Function):
         w = weight.detach().float().contiguous()
         b = bias.detach().float().contiguous() if bias is not None else None
         y = torch.empty_like(x)
-        with torch.cuda.device(x.device):
+        with _vah.on(x.device):
             _vah.check(_vah.lib.vah_dwconv3x3_tokens_bf16(
                 x.data_ptr(), w.data_ptr(), b.data_ptr() if b is not None else None, B, H, W, C, 0,
                 y.data_ptr(), _stream(x)), 'dwconv_fwd')
@@ -689,7 +689,7 @@ class _DWConvTokens(torch.autograd.Function):
         dx = torch.empty_like(x)
         dw = torch.empty(C * 9 + C, dtype=torch.float32, device=x.device)
         ws = _scratch(10 * C, x.device)
-        with torch.cuda.device(x.device):
+        with _vah.on(x.device):
             _vah.check(_vah.lib.vah_dwconv3x3_tokens_bf16(
                 g.data_ptr(), w.data_ptr(), None, B, H, W, C, 1, dx.data_ptr(), _stream(x)), 'dwconv_dgrad')
             _vah.check(_vah.lib.vah_dwconv3x3_tokens_wgrad_bf16(
@@ -741,7 +741,7 @@ class _BNTail(torch.autograd.Function):
         group = _sync_group(norm) if training else None
         w = weight.detach().float().contiguous() if weight is not None else None
         bb = bias.detach().float().contiguous() if bias is not None else None
-        with torch.cuda.device(dev):
+        with _vah.on(dev):
             if training:
                 sums = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
                 ws = torch.empty(_vah.lib.vah_bn_tail_ws_floats(C), dtype=torch.float32, device=dev)
@@ -790,7 +790,7 @@ class _BNTail(torch.autograd.Function):
                scale, N, C, H, W)
         wp = w.data_ptr() if w is not None else None
         bp = bb.data_ptr() if bb is not None else None
-        with torch.cuda.device(dev):
+        with _vah.on(dev):
             sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
             ws = torch.empty(_vah.lib.vah_bn_tail_ws_floats(C), dtype=torch.float32, device=dev)
             _vah.check(_vah.lib.vah_bn_tail_bwd_stats(*ops, mean.data_ptr(), rstd.data_ptr(), wp, bp, int(relu), shp,
@@ -898,7 +898,7 @@ class _TokensToMaps(torch.autograd.Function):
         B, T, C = tokens.shape
         tokens = tokens.contiguous()
         outs, t0 = [], 0
-        with torch.cuda.device(tokens.device):
+        with _vah.on(tokens.device):
             for h, w in hw:
                 o = torch.empty((B, C, h, w), dtype=torch.float32, device=tokens.device)
                 _vah.check(_vah.lib.vah_transpose_tokens(tokens.data_ptr(), B, T, t0, h * w, C, o.data_ptr(), 1, 0, None,
@@ -915,7 +915,7 @@ class _TokensToMaps(torch.autograd.Function):
         dev = next(g.device for g in grads if g is not None)
         gt = torch.empty((B, T, C), dtype=torch.float32, device=dev)
         t0 = 0
-        with torch.cuda.device(dev):
+        with _vah.on(dev):
             for (h, w), g in zip(ctx.hw, grads):
                 if g is None:
                     gt[:, t0:t0 + h * w].zero_()
@@ -958,7 +958,7 @@ class _MapsToTokens(torch.autograd.Function):
         dev = maps[0].device
         out = torch.empty((B, T, C), dtype=torch.float32, device=dev)
         t0 = 0
-        with torch.cuda.device(dev):
+        with _vah.on(dev):
             for m, v, (h, w) in zip(maps, vecs, hw):
                 m = m.contiguous()
                 vv = v.detach().float().contiguous() if v is not None else None
@@ -974,7 +974,7 @@ class _MapsToTokens(torch.autograd.Function):
         hw, dts, has_vec, (B, T, C) = ctx.meta
         g = g.contiguous().float()
         gmaps, gvecs, t0 = [], [], 0
-        with torch.cuda.device(g.device):
+        with _vah.on(g.device):
             for (h, w), dt, hv in zip(hw, dts, has_vec):
                 gm = torch.empty((B, C, h, w), dtype=dt, device=g.device)
                 _vah.check(_vah.lib.vah_transpose_tokens(g.data_ptr(), B, T, t0, h * w, C, gm.data_ptr(), 1,
@@ -1011,7 +1011,7 @@ class _MaxPool3s2(torch.autograd.Function):
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
         y = torch.empty((N, C, Ho, Wo), dtype=torch.bfloat16, device=x.device)
         idx = torch.empty((N, C, Ho, Wo), dtype=torch.uint8, device=x.device)
-        with torch.cuda.device(x.device):
+        with _vah.on(x.device):
             _vah.check(_vah.lib.vah_maxpool3s2_fwd_bf16(x.data_ptr(), N * C, H, W, y.data_ptr(), idx.data_ptr(),
                                                         _stream(x)), 'maxpool_fwd')
         ctx.save_for_backward(idx)
@@ -1024,7 +1024,7 @@ class _MaxPool3s2(torch.autograd.Function):
         N, C, H, W = ctx.shape
         gy = gy.contiguous().to(torch.bfloat16)
         gx = torch.empty((N, C, H, W), dtype=torch.bfloat16, device=gy.device)
-        with torch.cuda.device(gy.device):
+        with _vah.on(gy.device):
             _vah.check(_vah.lib.vah_maxpool3s2_bwd_bf16(gy.data_ptr(), idx.data_ptr(), N * C, H, W, gx.data_ptr(),
                                                         _stream(gy)), 'maxpool_bwd')
         return gx

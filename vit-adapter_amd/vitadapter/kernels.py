@@ -37,7 +37,7 @@ class _FlashAttention(torch.autograd.Function):
         ws = torch.empty((B * H * hd * Np,), dtype=qkv.dtype, device=qkv.device)
         base = qkv.data_ptr()
         esz = qkv.element_size()
-        with torch.cuda.device(qkv.device):
+        with _vah.on(qkv.device):
             rc = _vah.lib.vah_attn_fwd_bf16(base, base + C * esz, base + 2 * C * esz, 3 * C, N * 3 * C,
                                             B, H, N, float(scale), ws.data_ptr(), out.data_ptr(), C,
                                             lse.data_ptr(), _stream(qkv))
@@ -60,7 +60,7 @@ def _attention_backward(qkv, out, lse, dout, scale):
     ws = torch.empty((_vah.lib.vah_attn_bwd_workspace_bytes(B, H, N),), dtype=torch.uint8,
                      device=qkv.device)
     base, dbase, esz = qkv.data_ptr(), dqkv.data_ptr(), qkv.element_size()
-    with torch.cuda.device(qkv.device):
+    with _vah.on(qkv.device):
         rc = _vah.lib.vah_attn_bwd_bf16(
             base, base + C * esz, base + 2 * C * esz, 3 * C, N * 3 * C, out.data_ptr(),
             dout.data_ptr(), C, lse.data_ptr(), B, H, N, float(scale), ws.data_ptr(),
@@ -89,7 +89,7 @@ class _FlashAttentionBias(torch.autograd.Function):
         out = torch.empty((B, N, H, hd), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
         base, esz = qkv.data_ptr(), qkv.element_size()
-        with torch.cuda.device(qkv.device):
+        with _vah.on(qkv.device):
             rc = _vah.lib.vah_attn_bias_fwd_bf16(base, base + C * esz, base + 2 * C * esz, 3 * C, N * 3 * C, B, H, N, float(scale),
                                                  bl.data_ptr(), Np, out.data_ptr(), C, lse.data_ptr(), _stream(qkv))
         _vah.check(rc, 'vah_attn_bias_fwd_bf16')
@@ -108,7 +108,7 @@ class _FlashAttentionBias(torch.autograd.Function):
         ds = torch.empty((B, H, N, Np), dtype=torch.bfloat16, device=qkv.device)
         delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
         base, dbase, esz = qkv.data_ptr(), dqkv.data_ptr(), qkv.element_size()
-        with torch.cuda.device(qkv.device):
+        with _vah.on(qkv.device):
             rc = _vah.lib.vah_attn_bias_bwd_bf16(
                 base, base + C * esz, base + 2 * C * esz, 3 * C, N * 3 * C, out.data_ptr(), dout.data_ptr(), C, lse.data_ptr(),
                 B, H, N, ctx.scale, bl.data_ptr(), blt.data_ptr(), Np, ds.data_ptr(), delta.data_ptr(), dbase, dbase + C * esz,
@@ -138,7 +138,7 @@ class _FlashAttentionRelPos(torch.autograd.Function):
         out = torch.empty((B, N, H, hd), dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
         base, esz = qkv.data_ptr(), qkv.element_size()
-        with torch.cuda.device(qkv.device):
+        with _vah.on(qkv.device):
             _vah.check(_vah.lib.vah_relpos_bias_build(tb.data_ptr(), index.data_ptr(), tb.shape[0], H, N, Np, bl.data_ptr(),
                                                       blt.data_ptr(), _stream(qkv)), 'vah_relpos_bias_build')
             rc = _vah.lib.vah_attn_bias_fwd_bf16(base, base + C * esz, base + 2 * C * esz, 3 * C, N * 3 * C, B, H, N, float(scale),
@@ -161,7 +161,7 @@ class _FlashAttentionRelPos(torch.autograd.Function):
         delta = torch.empty((B, H, N), dtype=torch.float32, device=qkv.device)
         base, dbase, esz = qkv.data_ptr(), dqkv.data_ptr(), qkv.element_size()
         dtable = None
-        with torch.cuda.device(qkv.device):
+        with _vah.on(qkv.device):
             rc = _vah.lib.vah_attn_bias_bwd_bf16(
                 base, base + C * esz, base + 2 * C * esz, 3 * C, N * 3 * C, out.data_ptr(), dout.data_ptr(), C, lse.data_ptr(),
                 B, H, N, ctx.scale, bl.data_ptr(), blt.data_ptr(), Np, ds.data_ptr(), delta.data_ptr(), dbase, dbase + C * esz,
@@ -196,7 +196,7 @@ class _WindowFlashAttention(torch.autograd.Function):
         ws = (torch.empty((Z * H * hd * _vah.lib.vah_attn_padded_len(Nw),), dtype=qkv.dtype, device=qkv.device)
               if Nw > _RESIDENT_WINDOW else None)
         base, esz = qkv.data_ptr(), qkv.element_size()
-        with torch.cuda.device(qkv.device):
+        with _vah.on(qkv.device):
             rc = _vah.lib.vah_attn_win_fwd_bf16(base, base + C * esz, base + 2 * C * esz, 3 * C, B, gh, gw,
                                                 win, H, float(scale), ws.data_ptr() if ws is not None else 0, out.data_ptr(), C,
                                                 lse.data_ptr(), _stream(qkv))
@@ -216,7 +216,7 @@ class _WindowFlashAttention(torch.autograd.Function):
         ws = (torch.empty((_vah.lib.vah_attn_bwd_workspace_bytes(Z, H, Nw),), dtype=torch.uint8, device=qkv.device)
               if Nw > _RESIDENT_WINDOW else None)
         base, dbase, esz = qkv.data_ptr(), dqkv.data_ptr(), qkv.element_size()
-        with torch.cuda.device(qkv.device):
+        with _vah.on(qkv.device):
             rc = _vah.lib.vah_attn_win_bwd_bf16(
                 base, base + C * esz, base + 2 * C * esz, 3 * C, out.data_ptr(), dout.data_ptr(), C,
                 lse.data_ptr(), B, gh, gw, win, H, scale, ws.data_ptr() if ws is not None else 0, dbase, dbase + C * esz,

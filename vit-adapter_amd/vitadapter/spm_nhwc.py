@@ -24,7 +24,7 @@ def image_to_nhwc16(x):
     assert C == 3 and x.dtype == torch.float32
     x = x.contiguous()
     y = torch.empty((N, H, W, 16), dtype=torch.bfloat16, device=x.device)
-    with torch.cuda.device(x.device):
+    with _vah.on(x.device):
         _vah.check(_vah.lib.vah_image_to_nhwc16_bf16(x.data_ptr(), N, H, W, y.data_ptr(), _stream(x)), 'image_to_nhwc16')
     return y
 
@@ -69,7 +69,7 @@ class _BNRelu(torch.autograd.Function):
         group = fused._sync_group(norm) if training else None
         w = weight.detach().float().contiguous() if weight is not None else None
         b = bias.detach().float().contiguous() if bias is not None else None
-        with torch.cuda.device(dev):
+        with _vah.on(dev):
             if training:
                 sums = torch.empty(2 * C + 1, dtype=torch.float32, device=dev)
                 ws = torch.empty(_vah.lib.vah_bn_nhwc_ws_floats(C), dtype=torch.float32, device=dev)
@@ -112,7 +112,7 @@ class _BNRelu(torch.autograd.Function):
         dev, st = x.device, _stream(x)
         wp = w.data_ptr() if w is not None else None
         bp = b.data_ptr() if b is not None else None
-        with torch.cuda.device(dev):
+        with _vah.on(dev):
             sums = torch.empty(2 * C, dtype=torch.float32, device=dev)
             ws = torch.empty(_vah.lib.vah_bn_nhwc_ws_floats(C), dtype=torch.float32, device=dev)
             _vah.check(_vah.lib.vah_bn_nhwc_bwd_stats(x.data_ptr(), dy.data_ptr(), rows, C, mean.data_ptr(), rstd.data_ptr(), wp,
@@ -145,7 +145,7 @@ class _MaxPool(torch.autograd.Function):
         x = x.contiguous()
         y = torch.empty((N, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C), dtype=x.dtype, device=x.device)
         idx = torch.empty(y.shape, dtype=torch.uint8, device=x.device)
-        with torch.cuda.device(x.device):
+        with _vah.on(x.device):
             _vah.check(_vah.lib.vah_maxpool3s2_nhwc_fwd_bf16(x.data_ptr(), N, H, W, C, y.data_ptr(), idx.data_ptr(), _stream(x)),
                        'maxpool_nhwc_fwd')
         ctx.save_for_backward(idx)
@@ -158,7 +158,7 @@ class _MaxPool(torch.autograd.Function):
         N, H, W, C = ctx.in_shape
         gy = gy.contiguous().to(torch.bfloat16)
         gx = torch.empty(ctx.in_shape, dtype=torch.bfloat16, device=gy.device)
-        with torch.cuda.device(gy.device):
+        with _vah.on(gy.device):
             _vah.check(_vah.lib.vah_maxpool3s2_nhwc_bwd_bf16(gy.data_ptr(), idx.data_ptr(), N, H, W, C, gx.data_ptr(), _stream(gy)),
                        'maxpool_nhwc_bwd')
         return gx
