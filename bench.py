@@ -51,6 +51,13 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--preset', default='base_det', help='vitadapter preset (base_det = BASELINE configs[2])')
     ap.add_argument('--size', type=int, nargs=2, default=[1024, 1024], metavar=('H', 'W'))
+    ap.add_argument('--hip-graph', action='store_true',
+                    help='single GPU only: capture one whole step (zero_grad, forward, backward, AdamW) into a HIP graph after '
+                         'the warm-up and time K replays of it; the per-kernel rows then come from K more eager steps '
+                         'outside the timed region.  Pays when the host, not the GPU, is the longer pole (the 24-block presets)')
+    ap.add_argument('--no-checkpoint', action='store_true',
+                    help='presets with with_cp=True (the large models: the reference recomputes activations to fit 32 GB '
+                         'cards): keep the activations instead - 288 GB of HBM holds them, same arithmetic')
     ap.add_argument('--batch', type=int, default=2, help='per-GPU batch')
     ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
     ap.add_argument('--cpu-baseline', default='auto', choices=['auto', 'full', 'small', 'none'],
@@ -327,7 +334,8 @@ def main_mock(args):
         print(json.dumps({'metric': 'mock', 'value': round(world * args.batch * args.steps / dt, 3), 'unit': 'images/sec',
                           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'data': 'mock',
                           'config': {'workload': 'mock step (launch-path rehearsal on CPU)', 'parallelism': 'dp%d' % world,
-                                     'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
+                                     'hip_graph': use_graph,
+                       'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
                                      'backend': 'gloo'}}), flush=True)
     if world > 1:
         dp.barrier()
@@ -356,10 +364,11 @@ def main():
     setup_gemm_tuning(args)
     preset_kw = dict(PRESETS[args.preset])
     torch.manual_seed(0)
-    model = build_preset(args.preset).to(dev).train()
+    model = build_preset(args.preset, **({'with_cp': False} if args.no_checkpoint else {})).to(dev).train()
     n_params = sum(p.numel() for p in model.parameters())
     net = dp.wrap(model, dev, bucket_cap_mb=64)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.05, fused=True)
+    use_graph = bool(args.hip_graph) and world == 1 and not args.no_optimizer
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.05, fused=True, capturable=use_graph)
     amp = torch.bfloat16 if args.dtype == 'bf16' else None
 
     H, W = args.size
@@ -380,17 +389,45 @@ def main():
         dp.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    _vah.prof_enable(True, args.profile_kernels)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    host_dt = time.perf_counter() - t0           # the host has enqueued every step; the GPU may still be running
-    fence()
-    dt = time.perf_counter() - t0
-    _vah.prof_enable(False)
+    if use_graph:
+        # warm-up on a side stream (allocator pools, GEMM algorithm choices, MIOpen find), then one captured step
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(args.warmup, 3)):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        fence()
+        graph = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            graph_loss = step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            graph.replay()
+        host_dt = time.perf_counter() - t0
+        fence()
+        dt = time.perf_counter() - t0
+        loss = graph_loss
+        # per-kernel rows: HIP events cannot be read back from inside a graph, so K eager steps, untimed
+        _vah.prof_enable(True, args.profile_kernels)
+        for _ in range(args.steps):
+            step()
+        fence()
+        _vah.prof_enable(False)
+    else:
+        for _ in range(args.warmup):
+            step()
+        fence()
+        _vah.prof_enable(True, args.profile_kernels)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        host_dt = time.perf_counter() - t0           # the host has enqueued every step; the GPU may still be running
+        fence()
+        dt = time.perf_counter() - t0
+        _vah.prof_enable(False)
     prof = _vah.prof_report()
     assert torch.isfinite(loss).item(), 'loss is not finite'
 
@@ -426,9 +463,11 @@ def main():
                                    'drop_path %.1f, SyncBN, %s' % (
                                        args.preset, preset_kw['flavour'], H, W, args.batch,
                                        preset_kw['drop_path_rate'],
-                                       'step = fwd+bwd' if args.no_optimizer else 'step = fwd+bwd+AdamW'),
+                                       ('step = fwd+bwd' if args.no_optimizer else 'step = fwd+bwd+AdamW')
+                                       + (', activations kept (with_cp off)' if args.no_checkpoint else '')),
                        'global_batch': world * args.batch, 'params_M': round(n_params / 1e6, 2),
                        'parallelism': 'dp%d' % world,
+                       'hip_graph': use_graph,
                        'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
                        'backend': args.backend if world > 1 else None},
             'roofline': roofline,
