@@ -334,7 +334,7 @@ def main_mock(args):
         print(json.dumps({'metric': 'mock', 'value': round(world * args.batch * args.steps / dt, 3), 'unit': 'images/sec',
                           'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'data': 'mock',
                           'config': {'workload': 'mock step (launch-path rehearsal on CPU)', 'parallelism': 'dp%d' % world,
-                                     'hip_graph': use_graph,
+                                     'hip_graph': False,
                        'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
                                      'backend': 'gloo'}}), flush=True)
     if world > 1:
@@ -467,6 +467,7 @@ def main():
                                        + (', activations kept (with_cp off)' if args.no_checkpoint else '')),
                        'global_batch': world * args.batch, 'params_M': round(n_params / 1e6, 2),
                        'parallelism': 'dp%d' % world,
+                       'hip_graph': use_graph,
                        'hip_graph': use_graph,
                        'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
                        'backend': args.backend if world > 1 else None},
