@@ -468,7 +468,6 @@ def main():
                        'global_batch': world * args.batch, 'params_M': round(n_params / 1e6, 2),
                        'parallelism': 'dp%d' % world,
                        'hip_graph': use_graph,
-                       'hip_graph': use_graph,
                        'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
                        'backend': args.backend if world > 1 else None},
             'roofline': roofline,
