@@ -344,6 +344,11 @@ int vah_bn_tail_bwd_apply(const void *a, int a_bf16, const void *b, int b_bf16, 
 int vah_bn_finalize_stats(const float *sums, int64_t C, float eps, float momentum, float *running_mean,
                           float *running_var, float *mean, float *rstd, void *stream);
 
+/* ConvTranspose2d(k = 2, stride 2) - the backbone's `up` (vit_adapter.py:46, 106-109) - runs as GEMMs on token rows
+ * (vah_gemm_bf16: U (B, 4*C, h*w), rows (dy, dx, co), = Wcat x rows^T); this pass interleaves the 2 x 2 sub-pixels:
+ * planes[b][co][2y+dy][2x+dx] = U[b][(2dy+dx)*C + co][y*w + x]  (inverse != 0: U <- planes, for the backward). */
+int vah_pixel_shuffle2_bf16(const void *src, int64_t B, int64_t C, int64_t h, int64_t w, void *dst, int inverse, void *stream);
+
 /* Token rows <-> NCHW planes.  to_planes != 0: dst (B, C, T) <- src (B, T_total, C) rows [t0, t0 + T);
  * else dst (B, T_total, C) rows [t0, t0 + T) <- src (B, C, T) + vec[C] (vec optional).  Tokens fp32, planes
  * fp32 or bf16.  Replaces c[:, a:b].transpose(1, 2).view(B, C, H, W).contiguous() of the pyramid assembly
@@ -396,6 +401,9 @@ int vah_conv3x3_wgrad_nhwc_bf16(const void *x, int64_t N, int64_t IH, int64_t IW
  * vah_maxpool3s2_nhwc_*: MaxPool2d(3, stride 2, padding 1) of the stem; idx (same shape as y, one byte per element) =
  *   window position 0..8 of the first maximum; the backward gathers (no atomics). */
 int vah_image_to_nhwc16_bf16(const float *x, int64_t N, int64_t H, int64_t W, void *y, void *stream);
+/* x (N, C, H, W) fp32 -> y (N * H/ps * W/ps, C*ps*ps) bf16, column (c, ky, kx): the patch embedding
+ * (PatchEmbed.proj, base/vit.py:169-190: Conv2d(k = stride = ps)) then is vah_gemm_bf16 of y with the flattened filters. */
+int vah_patchify_bf16(const float *x, int64_t N, int64_t C, int64_t H, int64_t W, int64_t ps, void *y, void *stream);
 int64_t vah_bn_nhwc_ws_floats(int64_t C);
 int vah_bn_nhwc_stats(const void *x, int64_t rows, int64_t C, float *sums, float *ws, void *stream);
 int vah_bn_nhwc_apply(const void *x, int64_t rows, int64_t C, const float *mean, const float *rstd, const float *w,

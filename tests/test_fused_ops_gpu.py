@@ -570,3 +570,53 @@ def test_layer_norm_dual_keep(shape):
             _close(g, w, tol, nm)
         if use[1]:
             _close(ya, na(x), 1e-2, 'ya')
+
+
+@pytest.mark.parametrize('B,h,w,C,Co', [(2, 8, 16, 64, 32), (1, 5, 8, 128, 128), (2, 32, 32, 768, 768)])
+def test_up_from_tokens_matches_conv_transpose(B, h, w, C, Co):
+    """ConvTranspose2d(k 2, s 2) as GEMMs on token rows + sub-pixel interleave (fused.up_from_tokens; reference
+    vit_adapter.py:46, 106-109) against F.conv_transpose2d in fp32 on the same bf16-rounded operands: output, d(rows),
+    d(weight)."""
+    import torch.nn.functional as F
+    from vitadapter import fused
+    torch.manual_seed(C + h)
+    up = torch.nn.ConvTranspose2d(C, Co, 2, 2).cuda()
+    rows = torch.randn(B, h * w, C, device='cuda', requires_grad=True)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        with fused.forward_epoch(up):
+            out = fused.up_from_tokens(up, rows, h, w)
+    assert out is not None and out.shape == (B, Co, 2 * h, 2 * w) and out.dtype == torch.bfloat16
+    g = torch.randn_like(out, dtype=torch.float32)
+    out.backward(g.to(torch.bfloat16))
+    rr = rows.detach().to(torch.bfloat16).float().requires_grad_(True)
+    wr = up.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    ref = F.conv_transpose2d(rr.transpose(1, 2).reshape(B, C, h, w), wr, None, stride=2)
+    ref.backward(g.to(torch.bfloat16).float())
+    _close(out.float(), ref, 2 ** -7, 'out')
+    _close(rows.grad, rr.grad, 2 ** -6, 'd rows')
+    _close(up.weight.grad, wr.grad, 2e-3, 'd weight')
+
+
+@pytest.mark.parametrize('B,H,W,E', [(2, 64, 96, 192), (1, 224, 224, 768)])
+def test_patch_embed_gemm_matches_conv(B, H, W, E):
+    """Patch embedding (Conv2d, kernel = stride = 16, base/vit.py:169-190) as one GEMM on bf16 patch rows against the
+    convolution in fp32 on the same bf16-rounded operands: tokens, d(weight), d(bias)."""
+    from vitadapter import fused
+    torch.manual_seed(E)
+    conv = torch.nn.Conv2d(3, E, 16, 16).cuda()
+    x = torch.randn(B, 3, H, W, device='cuda')
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        with fused.forward_epoch(conv):
+            out = fused.patch_embed(conv, x)
+    assert out is not None
+    tok, Hp, Wp = out
+    assert (Hp, Wp) == (H // 16, W // 16) and tok.shape == (B, Hp * Wp, E)
+    g = torch.randn(tok.shape, device='cuda')
+    tok.backward(g.to(tok.dtype))
+    wr = conv.weight.detach().to(torch.bfloat16).float().requires_grad_(True)
+    br = conv.bias.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(x.to(torch.bfloat16).float(), wr, br, stride=16).flatten(2).transpose(1, 2)
+    ref.backward(g.to(torch.bfloat16).float())
+    _close(tok.float(), ref, 2 ** -7, 'tokens')
+    _close(conv.weight.grad, wr.grad, 2e-3, 'd weight')
+    _close(conv.bias.grad, br.grad, 2e-3, 'd bias')

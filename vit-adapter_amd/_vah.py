@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
-ABI_VERSION = 31
+ABI_VERSION = 33
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -119,6 +119,7 @@ lib.vah_conv3x3_wgrad_ws_floats.argtypes = [_i64, _i64]
 lib.vah_conv3x3_wgrad_ws_floats.restype = _i64
 lib.vah_conv3x3_wgrad_nhwc_bf16.argtypes = [_p, _i64, _i64, _i64, _i64, _p, _i64, _i64, _i64, _int, _p, _i64, _p, _p]
 lib.vah_image_to_nhwc16_bf16.argtypes = [_p, _i64, _i64, _i64, _p, _p]
+lib.vah_patchify_bf16.argtypes = [_p, _i64, _i64, _i64, _i64, _i64, _p, _p]
 lib.vah_bn_nhwc_ws_floats.argtypes = [_i64]
 lib.vah_bn_nhwc_ws_floats.restype = _i64
 lib.vah_bn_nhwc_stats.argtypes = [_p, _i64, _i64, _p, _p, _p]
@@ -127,6 +128,7 @@ lib.vah_bn_nhwc_bwd_stats.argtypes = [_p, _p, _i64, _i64, _p, _p, _p, _p, _int, 
 lib.vah_bn_nhwc_bwd_apply.argtypes = [_p, _p, _i64, _i64, _p, _p, _p, _p, _int, _p, _p, _p, _p]
 lib.vah_maxpool3s2_nhwc_fwd_bf16.argtypes = [_p, _i64, _i64, _i64, _i64, _p, _p, _p]
 lib.vah_maxpool3s2_nhwc_bwd_bf16.argtypes = [_p, _p, _i64, _i64, _i64, _i64, _p, _p]
+lib.vah_pixel_shuffle2_bf16.argtypes = [_p, _i64, _i64, _i64, _i64, _p, _int, _p]
 lib.vah_transpose_tokens.argtypes = [_p, _i64, _i64, _i64, _i64, _i64, _p, _int, _int, _p, _p]
 lib.vah_reduce_ws_floats.argtypes = [_i64]
 lib.vah_reduce_ws_floats.restype = _i64
@@ -140,7 +142,7 @@ for _n in ('vah_layernorm_fwd_f32_bf16', 'vah_layernorm_bwd_f32_bf16', 'vah_scal
            'vah_bn_tail_stats', 'vah_bn_tail_apply', 'vah_bn_tail_bwd_stats', 'vah_bn_tail_bwd_apply',
            'vah_bn_finalize_stats', 'vah_transpose_tokens', 'vah_maxpool3s2_fwd_bf16', 'vah_maxpool3s2_bwd_bf16',
            'vah_conv_taps_nhwc_bf16', 'vah_conv3x3_dgrad_nhwc_bf16', 'vah_conv3x3_wgrad_nhwc_bf16',
-           'vah_attn_bias_fwd_bf16', 'vah_attn_bias_bwd_bf16', 'vah_relpos_bias_build', 'vah_relpos_bias_grad', 'vah_image_to_nhwc16_bf16', 'vah_bn_nhwc_stats', 'vah_bn_nhwc_apply', 'vah_bn_nhwc_bwd_stats', 'vah_bn_nhwc_bwd_apply',
+           'vah_pixel_shuffle2_bf16', 'vah_patchify_bf16', 'vah_attn_bias_fwd_bf16', 'vah_attn_bias_bwd_bf16', 'vah_relpos_bias_build', 'vah_relpos_bias_grad', 'vah_image_to_nhwc16_bf16', 'vah_bn_nhwc_stats', 'vah_bn_nhwc_apply', 'vah_bn_nhwc_bwd_stats', 'vah_bn_nhwc_bwd_apply',
            'vah_maxpool3s2_nhwc_fwd_bf16', 'vah_maxpool3s2_nhwc_bwd_bf16'):
     getattr(lib, _n).restype = ctypes.c_int
 
@@ -155,7 +157,7 @@ EXPORTS = (
     'vah_msda_backward_f32', 'vah_msda_backward_f64',
     'vah_msda_fused_supported', 'vah_msda_fused_forward', 'vah_msda_fused_backward',
     'vah_msda_fused_forward_win', 'vah_msda_tile_ws_bytes', 'vah_msda_backward_tiled_f32', 'vah_msda_fused_backward_tiled',
-    'vah_attn_bias_fwd_bf16', 'vah_attn_bias_bwd_bf16', 'vah_relpos_bias_build', 'vah_relpos_bias_grad_ws_floats',
+    'vah_pixel_shuffle2_bf16', 'vah_patchify_bf16', 'vah_attn_bias_fwd_bf16', 'vah_attn_bias_bwd_bf16', 'vah_relpos_bias_build', 'vah_relpos_bias_grad_ws_floats',
     'vah_relpos_bias_grad', 'vah_attn_padded_len', 'vah_attn_fwd_bf16', 'vah_attn_bwd_workspace_bytes', 'vah_attn_bwd_bf16',
     'vah_attn_win_fwd_bf16', 'vah_attn_win_bwd_bf16',
     'vah_reduce_ws_floats', 'vah_layernorm_fwd_f32_bf16', 'vah_layernorm_bwd_f32_bf16', 'vah_scale_residual_fwd',

@@ -40,6 +40,33 @@ __global__ __launch_bounds__(256) void image_to_nhwc16_kernel(const float *__res
     *reinterpret_cast<bf16x8 *>(y + i * 16 + 8) = z;
 }
 
+// image (N, C, H, W) fp32 -> patch rows (N * H/ps * W/ps, C * ps * ps) bf16, column = (c, ky, kx): the operand of the
+// patch embedding as a GEMM (a ps x ps / stride ps convolution is a matrix product of the patch rows with the
+// flattened filters).  One thread: 8 consecutive kx of one (patch, c, ky).
+__global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__ x, int C, int H, int W, int ps, int64_t items,
+                                                       __bf16 *__restrict__ y) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= items) return;
+    const int k8 = ps >> 3, Wp = W / ps, Hp = H / ps;
+    int64_t t = i;
+    const int kx8 = (int)(t % k8);
+    t /= k8;
+    const int ky = (int)(t % ps);
+    t /= ps;
+    const int c = (int)(t % C);
+    t /= C;
+    const int px = (int)(t % Wp);
+    t /= Wp;
+    const int py = (int)(t % Hp), n = (int)(t / Hp);
+    const float *src = x + (((int64_t)n * C + c) * H + py * ps + ky) * W + px * ps + kx8 * 8;
+    const float4 a = *reinterpret_cast<const float4 *>(src), b = *reinterpret_cast<const float4 *>(src + 4);
+    bf16x8 o;
+    o[0] = (__bf16)a.x, o[1] = (__bf16)a.y, o[2] = (__bf16)a.z, o[3] = (__bf16)a.w;
+    o[4] = (__bf16)b.x, o[5] = (__bf16)b.y, o[6] = (__bf16)b.z, o[7] = (__bf16)b.w;
+    const int64_t row = ((int64_t)n * Hp + py) * Wp + px;
+    *reinterpret_cast<bf16x8 *>(y + row * ((int64_t)C * ps * ps) + ((int64_t)c * ps + ky) * ps + kx8 * 8) = o;
+}
+
 struct BnParams {
     const float *mean, *rstd, *w, *b;
 };
@@ -394,6 +421,22 @@ int vah_maxpool3s2_nhwc_bwd_bf16(const void *gy, const void *idx, int64_t N, int
     LaunchScope scope("spm_maxpool_bwd", N * H * W * C * 2 + N * OH * OW * C * 3, (hipStream_t)stream);
     hipLaunchKernelGGL(maxpool_nhwc_bwd_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        (const __bf16 *)gy, (const uint8_t *)idx, (int)N, (int)H, (int)W, (int)C, (int)OH, (int)OW, (__bf16 *)gx);
+    return check_launch(fn);
+}
+
+
+int vah_patchify_bf16(const float *x, int64_t N, int64_t C, int64_t H, int64_t W, int64_t ps, void *y, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_patchify_bf16";
+    if (N < 0 || C < 1 || ps < 8 || ps % 8 || H < ps || W < ps || H % ps || W % ps) return fail(VAH_E_SHAPE, "%s: bad dims", fn);
+    if (N == 0) return VAH_OK;
+    if (!x || !y) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if (((uintptr_t)x | (uintptr_t)y) % 16) return fail(VAH_E_ALIGN, "%s: 16-byte alignment", fn);
+    const int64_t items = N * C * H * W / 8;
+    LaunchScope scope("patchify", N * C * H * W * 6, (hipStream_t)stream);
+    hipLaunchKernelGGL(patchify_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, (int)C, (int)H,
+                       (int)W, (int)ps, items, (__bf16 *)y);
     return check_launch(fn);
 }
 

@@ -594,6 +594,50 @@ int fill_operands(const char *fn, Operands &o, const void *a, int a_bf16, const 
     return VAH_OK;
 }
 
+
+// ConvTranspose2d(k = 2, stride 2) as GEMMs on token rows: the product U (B, 4 * C, h * w), rows (dy, dx, co), is the
+// transposed convolution's output with its 2 x 2 sub-pixels still apart; this pass interleaves them into NCHW planes
+//   out[b][co][2 y + dy][2 x + dx] = U[b][(2 dy + dx) * C + co][y * w + x]            (inverse: the other way round)
+// One thread: 8 consecutive x of one source row pair (dx = 0, 1) <-> 16 consecutive output pixels (16-byte accesses).
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 ps_bf16x8;
+template <bool INVERSE>
+__global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const __bf16 *__restrict__ src, __bf16 *__restrict__ dst, int B, int C,
+                                                             int h, int w, int64_t items) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (b, co, Y, x8)
+    if (i >= items) return;
+    const int w8 = w >> 3;
+    const int x8 = (int)(i % w8);
+    int64_t t = i / w8;
+    const int Y = (int)(t % (2 * h));
+    t /= 2 * h;
+    const int co = (int)(t % C), b = (int)(t / C);
+    const int y = Y >> 1, dy = Y & 1;
+    const int64_t u0 = (((int64_t)b * 4 + 2 * dy) * C + co) * ((int64_t)h * w) + (int64_t)y * w + 8 * x8;       // dx = 0 row
+    const int64_t u1 = u0 + (int64_t)C * h * w;                                                                  // dx = 1 row
+    const int64_t o = (((int64_t)b * C + co) * (2 * h) + Y) * (2 * (int64_t)w) + 16 * x8;
+    if (!INVERSE) {
+        const ps_bf16x8 a = *reinterpret_cast<const ps_bf16x8 *>(src + u0), c = *reinterpret_cast<const ps_bf16x8 *>(src + u1);
+        ps_bf16x8 lo, hi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            lo[2 * j] = a[j], lo[2 * j + 1] = c[j];
+            hi[2 * j] = a[4 + j], hi[2 * j + 1] = c[4 + j];
+        }
+        *reinterpret_cast<ps_bf16x8 *>(dst + o) = lo;
+        *reinterpret_cast<ps_bf16x8 *>(dst + o + 8) = hi;
+    } else {
+        const ps_bf16x8 lo = *reinterpret_cast<const ps_bf16x8 *>(src + o), hi = *reinterpret_cast<const ps_bf16x8 *>(src + o + 8);
+        ps_bf16x8 a, c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = lo[2 * j], c[j] = lo[2 * j + 1];
+            a[4 + j] = hi[2 * j], c[4 + j] = hi[2 * j + 1];
+        }
+        *reinterpret_cast<ps_bf16x8 *>(dst + u0) = a;
+        *reinterpret_cast<ps_bf16x8 *>(dst + u1) = c;
+    }
+}
+
 }  // namespace
 }  // namespace vah
 
@@ -764,6 +808,28 @@ int vah_maxpool3s2_bwd_bf16(const void *gy, const void *idx, int64_t planes, int
     hipLaunchKernelGGL(maxpool3s2_bwd_kernel, dim3((unsigned)((W + 511) / 512), (unsigned)((H + 3) / 4), (unsigned)planes),
                        dim3(256), 0, st, (const __bf16 *)gy, (const unsigned char *)idx, (int)H, (int)W, (int)Ho, (int)Wo,
                        (__bf16 *)gx);
+    return check_launch(fn);
+}
+
+
+/* inverse == 0: planes (B, C, 2h, 2w) <- U (B, 4*C, h*w), rows (dy, dx, co); inverse != 0: U <- planes.  bf16, w % 8 == 0. */
+int vah_pixel_shuffle2_bf16(const void *src, int64_t B, int64_t C, int64_t h, int64_t w, void *dst, int inverse, void *stream) {
+    using namespace vah;
+    clear_error();
+    const char *fn = "vah_pixel_shuffle2_bf16";
+    if (B < 0 || C < 1 || h < 1 || w < 8 || w % 8) return fail(VAH_E_SHAPE, "%s: w must be a multiple of 8", fn);
+    if (B == 0) return VAH_OK;
+    if (!src || !dst) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    if (((uintptr_t)src | (uintptr_t)dst) % 16) return fail(VAH_E_ALIGN, "%s: 16-byte alignment", fn);
+    const int64_t items = B * C * 2 * h * (w / 8);
+    hipStream_t st = (hipStream_t)stream;
+    LaunchScope scope("pixel_shuffle2", B * C * 4 * h * w * 4, st);
+    if (inverse)
+        hipLaunchKernelGGL(pixel_shuffle2_kernel<true>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, (const __bf16 *)src,
+                           (__bf16 *)dst, (int)B, (int)C, (int)h, (int)w, items);
+    else
+        hipLaunchKernelGGL(pixel_shuffle2_kernel<false>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, (const __bf16 *)src,
+                           (__bf16 *)dst, (int)B, (int)C, (int)h, (int)w, items);
     return check_launch(fn);
 }
 

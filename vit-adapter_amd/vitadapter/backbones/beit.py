@@ -182,6 +182,9 @@ class PatchEmbed(nn.Module):
         self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=patch_size, stride=patch_size)
 
     def forward(self, x, **kwargs):
+        out = fused.patch_embed(self.proj, x)              # bf16 autocast on the GPU: one GEMM on patch rows
+        if out is not None:
+            return out
         x = self.proj(x)
         Hp, Wp = x.shape[2], x.shape[3]
         return x.flatten(2).transpose(1, 2), Hp, Wp

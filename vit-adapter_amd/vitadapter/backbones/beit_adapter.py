@@ -101,7 +101,9 @@ class BEiTAdapter(BEiT):
         if self.add_vit_feature:
             x1, x2, x3, x4 = outs
             c4 = c4 + fused.halve(x4)
-            up = F.conv_transpose2d(c2, self.up.weight, None, stride=2) if fold else self.up(c2)
+            up = fused.up_from_tokens(self.up, c[:, :4 * H * W], 2 * H, 2 * W) if fold else None     # GEMM form on the token rows
+            if up is None:
+                up = F.conv_transpose2d(c2, self.up.weight, None, stride=2) if fold else self.up(c2)
             shift = self.spm.fc1.bias + self.up.bias if fold else None
             return [fused.bn_tail(self.norm1, up, c1, x1, 4, shift), fused.bn_tail(self.norm2, c2, None, x2, 2),
                     fused.bn_tail(self.norm3, c3, None, x3, 1), self.norm4(c4)]

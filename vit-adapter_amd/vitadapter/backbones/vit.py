@@ -73,6 +73,10 @@ class PatchEmbed(nn.Module):
         self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
 
     def forward(self, x):
+        if self.flatten:
+            out = fused.patch_embed(self.proj, x)          # bf16 autocast on the GPU: one GEMM on patch rows
+            if out is not None:
+                return self.norm(out[0]), out[1], out[2]
         x = self.proj(x)
         H, W = x.shape[-2:]
         if self.flatten:

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 import _vah
 
 ENABLED = {'layer_norm': True, 'residual': True, 'residual_ln': True, 'dwconv': True, 'linear': True, 'bn_tail': True,
-           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True, 'maps_in': True, 'linear_pair': True, 'maxpool': True, 'conv1x1': True, 'ln_dual': True, 'wgrad_fin': True, 'spm_nhwc': True}
+           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True, 'maps_in': True, 'linear_pair': True, 'maxpool': True, 'conv1x1': True, 'ln_dual': True, 'wgrad_fin': True, 'spm_nhwc': True, 'up_gemm': True, 'patch_gemm': True}
 for _k in os.environ.get('VAH_FUSED_DISABLE', '').split(','):      # e.g. VAH_FUSED_DISABLE=residual_ln,bn_tail (A/B runs)
     if _k:
         ENABLED[_k.strip()] = False
@@ -510,6 +510,88 @@ class _Conv1x1BF16(torch.autograd.Function):
                 dw = part if dw is None else dw.add_(part)
             dw = dw.view(Co, Ci, 1, 1)
         return dx, dw
+
+
+class _UpFromTokens(torch.autograd.Function):
+    """ConvTranspose2d(C, Co, kernel 2, stride 2) WITHOUT bias applied to a map given as its token rows:
+    rows (B, h*w, C) -> NCHW planes (B, Co, 2h, 2w) bf16.  The transposed convolution with stride = kernel is a plain
+    GEMM per image, U_b (4*Co, h*w) = Wcat (4*Co, C) rows_b^T with Wcat rows (dy, dx, co), followed by the 2 x 2 sub-pixel
+    interleave (csrc/tail_ops.hip::pixel_shuffle2); the backward is the inverse interleave and two GEMMs.  MIOpen's
+    NCHW transposed convolution took 494 + 846 us for this layer at base_det (2 x 768 x 128 x 128)."""
+
+    @staticmethod
+    def forward(ctx, rows, weight, h, w):
+        B, T, C = rows.shape
+        Co = weight.shape[1]
+        xb = rows.detach().to(torch.bfloat16).contiguous()
+        wc = BF16_COPIES.get(weight).permute(2, 3, 1, 0).reshape(4 * Co, C).contiguous()       # rows (dy, dx, co)
+        U = torch.empty((B, 4 * Co, T), dtype=torch.bfloat16, device=rows.device)
+        for b in range(B):
+            gemm_bf16(wc, xb[b], trans_b=True, out=U[b])
+        out = torch.empty((B, Co, 2 * h, 2 * w), dtype=torch.bfloat16, device=rows.device)
+        with _vah.on(rows.device):
+            _vah.check(_vah.lib.vah_pixel_shuffle2_bf16(U.data_ptr(), B, Co, h, w, out.data_ptr(), 0, _stream(rows)), 'pixel_shuffle2')
+        ctx.save_for_backward(xb, wc)
+        ctx.meta = (h, w, Co, rows.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xb, wc = ctx.saved_tensors
+        h, w, Co, in_dtype = ctx.meta
+        B, T, C = xb.shape
+        g = g.contiguous().to(torch.bfloat16)
+        dU = torch.empty((B, 4 * Co, T), dtype=torch.bfloat16, device=g.device)
+        with _vah.on(g.device):
+            _vah.check(_vah.lib.vah_pixel_shuffle2_bf16(g.data_ptr(), B, Co, h, w, dU.data_ptr(), 1, _stream(g)), 'pixel_shuffle2')
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((B, T, C), dtype=torch.bfloat16, device=g.device)
+            for b in range(B):
+                gemm_bf16(dU[b], wc, trans_a=True, out=dx[b])
+            if dx.dtype != in_dtype:
+                dx = dx.to(in_dtype)
+        if ctx.needs_input_grad[1]:
+            for b in range(B):
+                part = gemm_bf16(dU[b], xb[b], out_dtype=torch.float32)
+                dw = part if dw is None else dw.add_(part)
+            dw = dw.view(2, 2, Co, C).permute(3, 2, 0, 1).contiguous()
+        return dx, dw, None, None
+
+
+def up_from_tokens(up, rows, h, w):
+    """``F.conv_transpose2d(rows.transpose(1, 2).view(B, C, h, w), up.weight, None, stride=2)`` for the backbone's
+    2 x 2 / stride 2 ``up`` (vit_adapter.py:46), from the token rows of the map and without the bias (the caller folds
+    it into the BatchNorm tail); None when the GEMM form does not apply."""
+    wt = up.weight
+    if (ENABLED['up_gemm'] and ENABLED['linear'] and rows.is_cuda and _bf16_autocast() and isinstance(up, torch.nn.ConvTranspose2d)
+            and up.kernel_size == (2, 2) and up.stride == (2, 2) and up.padding == (0, 0) and up.output_padding == (0, 0)
+            and up.groups == 1 and up.dilation == (1, 1) and wt.dtype == torch.float32 and rows.dim() == 3
+            and rows.shape[1] == h * w and rows.shape[2] == wt.shape[0] and w % 8 == 0 and wt.shape[0] % 8 == 0
+            and wt.shape[1] % 8 == 0 and rows.dtype in (torch.float32, torch.bfloat16) and rows.numel() > 0):
+        return _UpFromTokens.apply(rows, wt, h, w)
+    return None
+
+
+def patch_embed(conv, x):
+    """``conv(x).flatten(2).transpose(1, 2)`` for the patch embedding (Conv2d with kernel = stride, base/vit.py:169-190)
+    as ONE GEMM on bf16 patch rows - no im2col / NCHW transposes; the rows come out in token order.  Returns
+    (tokens (B, N, E) bf16, H/ps, W/ps) or None when the form does not apply (input gradient wanted, other geometry)."""
+    w = conv.weight
+    ps = conv.kernel_size[0]
+    if (ENABLED['patch_gemm'] and ENABLED['linear'] and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad
+            and _bf16_autocast() and x.dim() == 4 and isinstance(conv, torch.nn.Conv2d) and conv.kernel_size == (ps, ps)
+            and conv.stride == (ps, ps) and conv.padding == (0, 0) and conv.groups == 1 and conv.dilation == (1, 1)
+            and ps % 8 == 0 and x.shape[2] % ps == 0 and x.shape[3] % ps == 0 and w.dtype == torch.float32
+            and w.shape[0] % 8 == 0 and x.numel() > 0):
+        B, C, H, W = x.shape
+        x = x.contiguous()
+        rows = torch.empty((B * (H // ps) * (W // ps), C * ps * ps), dtype=torch.bfloat16, device=x.device)
+        with _vah.on(x.device):
+            _vah.check(_vah.lib.vah_patchify_bf16(x.data_ptr(), B, C, H, W, ps, rows.data_ptr(), _stream(x)), 'patchify')
+        y = _LinearBF16.apply(rows, w.view(w.shape[0], -1), conv.bias)
+        return y.view(B, (H // ps) * (W // ps), w.shape[0]), H // ps, W // ps
+    return None
 
 
 def conv1x1(conv, x):

@@ -201,7 +201,8 @@ class _Conv1x1ToPlanes(torch.autograd.Function):
 def usable(spm, x):
     """The NHWC path serves the module as the reference builds it (3x3 / padding 1 / bias-free convolutions with
     64-multiple widths, (Sync)BatchNorm + ReLU, the 3/2/1 max-pool) on a CUDA fp32 image under bf16 autocast."""
-    if not (fused.ENABLED.get('spm_nhwc', True) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] == 3
+    # the image's own gradient is not produced by this path: an input that requires grad takes the module as written
+    if not (fused.ENABLED.get('spm_nhwc', True) and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad and x.dim() == 4 and x.shape[1] == 3
             and fused._bf16_autocast() and x.shape[2] % 32 == 0 and x.shape[3] % 32 == 0 and x.numel() > 0):
         return False
     convs = [spm.stem[0], spm.stem[3], spm.stem[6], spm.conv2[0], spm.conv3[0], spm.conv4[0]]
