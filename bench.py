@@ -12,6 +12,13 @@ MSDeformAttn core runs on bf16 values / offsets / logits with fp32 accumulation,
 bf16 MFMA tiles) -> loss = sum_k mean(f_k) -> backward (+ gradient all-reduce) -> fused AdamW
 update.  Inputs are resident in HBM before the timed region.
 
+One GPU (default `--hip-graph auto`): after the warm-up ONE step is captured into a HIP graph and the timed region is
+K replays of it - every kernel of the step, 0.3 ms of host time instead of 24-28 ms (the eager loop is host-bound on the
+slower-CPU boxes of the pool: 69.3 img/s there against 72.5-72.8 on the others and 73.7 replayed).  HIP events cannot be
+read back from inside a graph, so the per-kernel rows below are taken from K more EAGER steps of the same process right
+after the timed region (`config.hip_graph`, `config.kernel_rows`).  `--hip-graph off` (and every N > 1 run: DDP's
+buckets are not captured) times the eager loop with the events inside the timed region.
+
 Rank 0 prints ONE JSON line with the contract fields plus
   "roofline":     the MSDA entry point with the largest total time in the timed region: bytes the
                   launch must move FOR THE DTYPES IT RUNS WITH / mean launch duration (HIP events
@@ -51,10 +58,12 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--preset', default='base_det', help='vitadapter preset (base_det = BASELINE configs[2])')
     ap.add_argument('--size', type=int, nargs=2, default=[1024, 1024], metavar=('H', 'W'))
-    ap.add_argument('--hip-graph', action='store_true',
-                    help='single GPU only: capture one whole step (zero_grad, forward, backward, AdamW) into a HIP graph after '
-                         'the warm-up and time K replays of it; the per-kernel rows then come from K more eager steps '
-                         'outside the timed region.  Pays when the host, not the GPU, is the longer pole (the 24-block presets)')
+    ap.add_argument('--hip-graph', default='auto', choices=['auto', 'on', 'off'],
+                    help='single GPU: capture one whole step (zero_grad, forward, backward, AdamW) into a HIP graph after the '
+                         'warm-up and time K replays of it (0.3 ms of host time per step instead of 24-28 ms); the per-kernel '
+                         'rows then come from K more EAGER steps right after the timed region, because HIP events cannot be '
+                         'read back from inside a graph.  auto: on for one GPU (eager if the capture fails), off for N > 1 '
+                         '(DDP buckets are not captured); off: the eager loop with the events inside the timed region')
     ap.add_argument('--no-checkpoint', action='store_true',
                     help='presets with with_cp=True (the large models: the reference recomputes activations to fit 32 GB '
                          'cards): keep the activations instead - 288 GB of HBM holds them, same arithmetic')
@@ -367,7 +376,7 @@ def main():
     model = build_preset(args.preset, **({'with_cp': False} if args.no_checkpoint else {})).to(dev).train()
     n_params = sum(p.numel() for p in model.parameters())
     net = dp.wrap(model, dev, bucket_cap_mb=64)
-    use_graph = bool(args.hip_graph) and world == 1 and not args.no_optimizer
+    use_graph = args.hip_graph != 'off' and world == 1 and not args.no_optimizer
     opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.05, fused=True, capturable=use_graph)
     amp = torch.bfloat16 if args.dtype == 'bf16' else None
 
@@ -389,8 +398,9 @@ def main():
         dp.barrier()
         torch.cuda.synchronize()
 
+    graph = None
     if use_graph:
-        # warm-up on a side stream (allocator pools, GEMM algorithm choices, MIOpen find), then one captured step
+        # warm-up on a side stream (allocator pools, GEMM algorithm choices), then one captured step
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -398,11 +408,22 @@ def main():
                 step()
         torch.cuda.current_stream().wait_stream(side)
         fence()
-        graph = torch.cuda.CUDAGraph()
-        opt.zero_grad(set_to_none=True)
-        with torch.cuda.graph(graph):
-            graph_loss = step()
-        fence()
+        try:
+            # the parameters' AccumulateGrad nodes were made on the warm-up stream; the capture stream differs by design
+            if hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
+                torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+            graph = torch.cuda.CUDAGraph()
+            opt.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                graph_loss = step()
+            fence()
+        except Exception as exc:                       # noqa: BLE001 - any capture failure: the eager loop below
+            if args.hip_graph == 'on':
+                raise
+            print('bench.py: HIP graph capture failed (%s: %s), timing the eager loop' % (type(exc).__name__, exc), file=sys.stderr)
+            graph, use_graph = None, False
+            torch.cuda.synchronize()
+    if graph is not None:
         t0 = time.perf_counter()
         for _ in range(args.steps):
             graph.replay()
@@ -468,6 +489,8 @@ def main():
                        'global_batch': world * args.batch, 'params_M': round(n_params / 1e6, 2),
                        'parallelism': 'dp%d' % world,
                        'hip_graph': use_graph,
+                       'kernel_rows': ('HIP events over %d eager steps right after the timed region (events cannot be read '
+                                       'back from inside a graph)' % args.steps) if use_graph else 'HIP events inside the timed region',
                        'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
                        'backend': args.backend if world > 1 else None},
             'roofline': roofline,
