@@ -74,3 +74,30 @@ def test_backward_uses_the_copy_of_its_own_forward_gpu():
     want = g.float() @ w0.to(torch.bfloat16).float()
     assert (gx.float() - want).abs().max().item() <= 2e-2 * max(1.0, want.abs().max().item())
     assert yb is not None
+
+
+def test_side_stream_deferral_rules():
+    """Weight gradients may stay on the side stream only when autograd will merely store them: leaf parameter without a
+    .grad, one use per forward epoch, no multi-rank process group (vitadapter/fused.py::_SideStream)."""
+    import torch
+    from vitadapter import fused
+    side = fused._SideStream()
+    p = torch.nn.Parameter(torch.zeros(4, 4))
+    dev = torch.device('cuda', 0)
+    fused.BF16_COPIES.epoch = 1            # an open forward epoch
+    try:
+        side.begin_epoch()
+        tok = side.note(p)
+        assert tok is not None and tok[0] == 1
+        tok2 = side.note(p)                # second use in the same forward: autograd will add the two gradients
+        assert tok2 is tok and tok[0] == 2
+        assert not side.may_defer(tok, dev) if torch.cuda.is_available() else True
+        side.begin_epoch()
+        p.grad = torch.zeros_like(p)       # gradient accumulation across micro-batches
+        assert side.note(p) is None
+        p.grad = None
+        assert side.note(p.view(16)) is None          # not a leaf
+        assert side.may_defer(None, dev) is False
+        assert side.may_defer(side.note(p), torch.device('cpu')) is False
+    finally:
+        fused.BF16_COPIES.epoch = 0
