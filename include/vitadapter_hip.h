@@ -347,7 +347,8 @@ int vah_bn_finalize_stats(const float *sums, int64_t C, float eps, float momentu
 /* ConvTranspose2d(k = 2, stride 2) - the backbone's `up` (vit_adapter.py:46, 106-109) - runs as GEMMs on token rows
  * (vah_gemm_bf16: U (B, 4*C, h*w), rows (dy, dx, co), = Wcat x rows^T); this pass interleaves the 2 x 2 sub-pixels:
  * planes[b][co][2y+dy][2x+dx] = U[b][(2dy+dx)*C + co][y*w + x]  (inverse != 0: U <- planes, for the backward). */
-int vah_pixel_shuffle2_bf16(const void *src, int64_t B, int64_t C, int64_t h, int64_t w, void *dst, int inverse, void *stream);
+int vah_pixel_shuffle2_bf16(const void *src, int64_t B, int64_t C, int64_t h, int64_t w, void *dst, int inverse, const void *add,
+                            void *stream);      /* add: planes-shaped bf16 addend of the forward (`up(c2) + c1`), or NULL */
 
 /* Token rows <-> NCHW planes.  to_planes != 0: dst (B, C, T) <- src (B, T_total, C) rows [t0, t0 + T);
  * else dst (B, T_total, C) rows [t0, t0 + T) <- src (B, C, T) + vec[C] (vec optional).  Tokens fp32, planes

@@ -63,9 +63,9 @@ def test_nhwc_batchnorm_and_pool_reject_bad_channels():
 
 
 def test_layout_kernels_reject_bad_widths():
-    assert lib.vah_pixel_shuffle2_bf16(P, 1, 8, 4, 12, P, 0, None) == E_SHAPE           # w % 8
-    assert lib.vah_pixel_shuffle2_bf16(P, 1, 8, 4, 16, None, 0, None) == E_NULL
-    assert lib.vah_pixel_shuffle2_bf16(P + 8, 1, 8, 4, 16, P, 1, None) == E_ALIGN
+    assert lib.vah_pixel_shuffle2_bf16(P, 1, 8, 4, 12, P, 0, None, None) == E_SHAPE           # w % 8
+    assert lib.vah_pixel_shuffle2_bf16(P, 1, 8, 4, 16, None, 0, None, None) == E_NULL
+    assert lib.vah_pixel_shuffle2_bf16(P + 8, 1, 8, 4, 16, P, 1, None, None) == E_ALIGN
     assert lib.vah_patchify_bf16(P, 1, 3, 64, 64, 12, P, None) == E_SHAPE                # patch size % 8
     assert lib.vah_patchify_bf16(P, 1, 3, 60, 64, 16, P, None) == E_SHAPE                # H % patch size
     assert lib.vah_patchify_bf16(None, 1, 3, 64, 64, 16, P, None) == E_NULL

@@ -595,6 +595,13 @@ def test_up_from_tokens_matches_conv_transpose(B, h, w, C, Co):
     _close(out.float(), ref, 2 ** -7, 'out')
     _close(rows.grad, rr.grad, 2 ** -6, 'd rows')
     _close(up.weight.grad, wr.grad, 2e-3, 'd weight')
+    # with the addend of the tail (`up(c2) + c1`): one rounding of the sum, gradient passed through unchanged
+    add = torch.randn(B, Co, 2 * h, 2 * w, device='cuda').to(torch.bfloat16).requires_grad_(True)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        out2 = fused.up_from_tokens(up, rows.detach(), h, w, add)
+    _close(out2.float(), ref.detach() + add.detach().float(), 2 ** -7, 'out + addend')
+    out2.backward(g.to(torch.bfloat16))
+    assert torch.equal(add.grad, g.to(torch.bfloat16))
 
 
 @pytest.mark.parametrize('B,H,W,E', [(2, 64, 96, 192), (1, 224, 224, 768)])

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
-ABI_VERSION = 33
+ABI_VERSION = 34
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -128,7 +128,7 @@ lib.vah_bn_nhwc_bwd_stats.argtypes = [_p, _p, _i64, _i64, _p, _p, _p, _p, _int, 
 lib.vah_bn_nhwc_bwd_apply.argtypes = [_p, _p, _i64, _i64, _p, _p, _p, _p, _int, _p, _p, _p, _p]
 lib.vah_maxpool3s2_nhwc_fwd_bf16.argtypes = [_p, _i64, _i64, _i64, _i64, _p, _p, _p]
 lib.vah_maxpool3s2_nhwc_bwd_bf16.argtypes = [_p, _p, _i64, _i64, _i64, _i64, _p, _p]
-lib.vah_pixel_shuffle2_bf16.argtypes = [_p, _i64, _i64, _i64, _i64, _p, _int, _p]
+lib.vah_pixel_shuffle2_bf16.argtypes = [_p, _i64, _i64, _i64, _i64, _p, _int, _p, _p]
 lib.vah_transpose_tokens.argtypes = [_p, _i64, _i64, _i64, _i64, _i64, _p, _int, _int, _p, _p]
 lib.vah_reduce_ws_floats.argtypes = [_i64]
 lib.vah_reduce_ws_floats.restype = _i64

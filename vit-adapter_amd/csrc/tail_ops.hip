@@ -600,9 +600,12 @@ int fill_operands(const char *fn, Operands &o, const void *a, int a_bf16, const 
 //   out[b][co][2 y + dy][2 x + dx] = U[b][(2 dy + dx) * C + co][y * w + x]            (inverse: the other way round)
 // One thread: 8 consecutive x of one source row pair (dx = 0, 1) <-> 16 consecutive output pixels (16-byte accesses).
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 ps_bf16x8;
+// `add` (forward only, planes-shaped bf16 or null): dst = interleave(src) + add, rounded once - the `up(c2) + c1` of
+// vit_adapter.py:107 in the precision autocast gives it (two bf16 tensors summed into bf16)
 template <bool INVERSE>
-__global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const __bf16 *__restrict__ src, __bf16 *__restrict__ dst, int B, int C,
-                                                             int h, int w, int64_t items) {
+__global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const __bf16 *__restrict__ src, __bf16 *__restrict__ dst,
+                                                             const __bf16 *__restrict__ add, int B, int C, int h, int w,
+                                                             int64_t items) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;          // (b, co, Y, x8)
     if (i >= items) return;
     const int w8 = w >> 3;
@@ -622,6 +625,14 @@ __global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const __bf16 *__res
         for (int j = 0; j < 4; ++j) {
             lo[2 * j] = a[j], lo[2 * j + 1] = c[j];
             hi[2 * j] = a[4 + j], hi[2 * j + 1] = c[4 + j];
+        }
+        if (add) {
+            const ps_bf16x8 p = *reinterpret_cast<const ps_bf16x8 *>(add + o), q = *reinterpret_cast<const ps_bf16x8 *>(add + o + 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                lo[j] = (__bf16)((float)lo[j] + (float)p[j]);
+                hi[j] = (__bf16)((float)hi[j] + (float)q[j]);
+            }
         }
         *reinterpret_cast<ps_bf16x8 *>(dst + o) = lo;
         *reinterpret_cast<ps_bf16x8 *>(dst + o + 8) = hi;
@@ -812,8 +823,10 @@ int vah_maxpool3s2_bwd_bf16(const void *gy, const void *idx, int64_t planes, int
 }
 
 
-/* inverse == 0: planes (B, C, 2h, 2w) <- U (B, 4*C, h*w), rows (dy, dx, co); inverse != 0: U <- planes.  bf16, w % 8 == 0. */
-int vah_pixel_shuffle2_bf16(const void *src, int64_t B, int64_t C, int64_t h, int64_t w, void *dst, int inverse, void *stream) {
+/* inverse == 0: planes (B, C, 2h, 2w) <- U (B, 4*C, h*w), rows (dy, dx, co) [+ add, planes-shaped, optional];
+ * inverse != 0: U <- planes.  bf16, w % 8 == 0. */
+int vah_pixel_shuffle2_bf16(const void *src, int64_t B, int64_t C, int64_t h, int64_t w, void *dst, int inverse, const void *add,
+                            void *stream) {
     using namespace vah;
     clear_error();
     const char *fn = "vah_pixel_shuffle2_bf16";
@@ -824,12 +837,13 @@ int vah_pixel_shuffle2_bf16(const void *src, int64_t B, int64_t C, int64_t h, in
     const int64_t items = B * C * 2 * h * (w / 8);
     hipStream_t st = (hipStream_t)stream;
     LaunchScope scope("pixel_shuffle2", B * C * 4 * h * w * 4, st);
+    if (add && (inverse || (uintptr_t)add % 16)) return fail(VAH_E_SHAPE, "%s: add is a forward-only, 16-byte aligned operand", fn);
     if (inverse)
         hipLaunchKernelGGL(pixel_shuffle2_kernel<true>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, (const __bf16 *)src,
-                           (__bf16 *)dst, (int)B, (int)C, (int)h, (int)w, items);
+                           (__bf16 *)dst, (const __bf16 *)nullptr, (int)B, (int)C, (int)h, (int)w, items);
     else
         hipLaunchKernelGGL(pixel_shuffle2_kernel<false>, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, (const __bf16 *)src,
-                           (__bf16 *)dst, (int)B, (int)C, (int)h, (int)w, items);
+                           (__bf16 *)dst, (const __bf16 *)add, (int)B, (int)C, (int)h, (int)w, items);
     return check_launch(fn);
 }
 

@@ -160,7 +160,10 @@ class ViTAdapter(TIMMVisionTransformer):
             # sum, upsampling and batch norm in one pair of passes (csrc/tail_ops.hip); off the bf16
             # GPU path fused.bn_tail evaluates exactly the reference expression
             c4 = c4 + fused.halve(x4)
-            up = fused.up_from_tokens(self.up, c[:, :4 * H * W], 2 * H, 2 * W) if fold else None     # GEMM form on the token rows
+            # GEMM form on the token rows, c1 summed in by its interleave pass (one bf16 operand for the tail instead of two)
+            up = fused.up_from_tokens(self.up, c[:, :4 * H * W], 2 * H, 2 * W, c1 if c1.dtype == torch.bfloat16 else None) if fold else None
+            if up is not None and c1.dtype == torch.bfloat16:
+                c1 = None
             if up is None:
                 up = F.conv_transpose2d(c2, self.up.weight, None, stride=2) if fold else self.up(c2)
             shift = self.spm.fc1.bias + self.up.bias if fold else None

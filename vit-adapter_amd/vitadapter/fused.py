@@ -597,7 +597,7 @@ class _UpFromTokens(torch.autograd.Function):
     NCHW transposed convolution took 494 + 846 us for this layer at base_det (2 x 768 x 128 x 128)."""
 
     @staticmethod
-    def forward(ctx, rows, weight, h, w):
+    def forward(ctx, rows, weight, h, w, addend):
         B, T, C = rows.shape
         Co = weight.shape[1]
         xb = rows.detach().to(torch.bfloat16).contiguous()
@@ -606,8 +606,10 @@ class _UpFromTokens(torch.autograd.Function):
         for b in range(B):
             gemm_bf16(wc, xb[b], trans_b=True, out=U[b])
         out = torch.empty((B, Co, 2 * h, 2 * w), dtype=torch.bfloat16, device=rows.device)
+        add = addend.contiguous() if addend is not None else None
         with _vah.on(rows.device):
-            _vah.check(_vah.lib.vah_pixel_shuffle2_bf16(U.data_ptr(), B, Co, h, w, out.data_ptr(), 0, _stream(rows)), 'pixel_shuffle2')
+            _vah.check(_vah.lib.vah_pixel_shuffle2_bf16(U.data_ptr(), B, Co, h, w, out.data_ptr(), 0,
+                                                        add.data_ptr() if add is not None else None, _stream(rows)), 'pixel_shuffle2')
         ctx.save_for_backward(xb, wc)
         ctx.meta = (h, w, Co, rows.dtype)
         return out
@@ -620,7 +622,7 @@ class _UpFromTokens(torch.autograd.Function):
         g = g.contiguous().to(torch.bfloat16)
         dU = torch.empty((B, 4 * Co, T), dtype=torch.bfloat16, device=g.device)
         with _vah.on(g.device):
-            _vah.check(_vah.lib.vah_pixel_shuffle2_bf16(g.data_ptr(), B, Co, h, w, dU.data_ptr(), 1, _stream(g)), 'pixel_shuffle2')
+            _vah.check(_vah.lib.vah_pixel_shuffle2_bf16(g.data_ptr(), B, Co, h, w, dU.data_ptr(), 1, None, _stream(g)), 'pixel_shuffle2')
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((B, T, C), dtype=torch.bfloat16, device=g.device)
@@ -633,20 +635,23 @@ class _UpFromTokens(torch.autograd.Function):
                 part = gemm_bf16(dU[b], xb[b], out_dtype=torch.float32)
                 dw = part if dw is None else dw.add_(part)
             dw = dw.view(2, 2, Co, C).permute(3, 2, 0, 1).contiguous()
-        return dx, dw, None, None
+        return dx, dw, None, None, (g if ctx.needs_input_grad[4] else None)      # d(out)/d(addend) = identity
 
 
-def up_from_tokens(up, rows, h, w):
+def up_from_tokens(up, rows, h, w, addend=None):
     """``F.conv_transpose2d(rows.transpose(1, 2).view(B, C, h, w), up.weight, None, stride=2)`` for the backbone's
     2 x 2 / stride 2 ``up`` (vit_adapter.py:46), from the token rows of the map and without the bias (the caller folds
-    it into the BatchNorm tail); None when the GEMM form does not apply."""
+    it into the BatchNorm tail); ``addend`` (planes-shaped bf16, e.g. c1) is summed in by the interleave pass -
+    ``up(c2) + c1`` rounded once to bf16, as autocast rounds the sum of two half tensors - so the tail reads one operand
+    instead of two.  None when the GEMM form does not apply."""
     wt = up.weight
     if (ENABLED['up_gemm'] and ENABLED['linear'] and rows.is_cuda and _bf16_autocast() and isinstance(up, torch.nn.ConvTranspose2d)
             and up.kernel_size == (2, 2) and up.stride == (2, 2) and up.padding == (0, 0) and up.output_padding == (0, 0)
             and up.groups == 1 and up.dilation == (1, 1) and wt.dtype == torch.float32 and rows.dim() == 3
             and rows.shape[1] == h * w and rows.shape[2] == wt.shape[0] and w % 8 == 0 and wt.shape[0] % 8 == 0
-            and wt.shape[1] % 8 == 0 and rows.dtype in (torch.float32, torch.bfloat16) and rows.numel() > 0):
-        return _UpFromTokens.apply(rows, wt, h, w)
+            and wt.shape[1] % 8 == 0 and rows.dtype in (torch.float32, torch.bfloat16) and rows.numel() > 0
+            and (addend is None or (addend.dtype == torch.bfloat16 and tuple(addend.shape) == (rows.shape[0], wt.shape[1], 2 * h, 2 * w)))):
+        return _UpFromTokens.apply(rows, wt, h, w, addend)
     return None
 
 
