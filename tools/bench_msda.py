@@ -17,17 +17,20 @@ from oracle import cases  # noqa: E402
 
 
 def timeit(fn, iters=20, warm=3):
+    """Median over ``iters`` of the HIP-event time of one call (seconds).  The median, not total / iters: one stall
+    inside the loop (an allocator refill, a clock ramp: 30-60 ms, seen about once per run of this script) would
+    otherwise land in whichever row it hit (2947 us instead of 190 us)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for e0, e1 in ev:
+        e0.record()
         fn()
-    e1.record()
+        e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters * 1e-3
+    times = sorted(e0.elapsed_time(e1) for e0, e1 in ev)
+    return times[len(times) // 2] * 1e-3
 
 
 def main():
