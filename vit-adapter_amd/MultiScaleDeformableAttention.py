@@ -65,7 +65,7 @@ def _common_checks(named, value, spatial_shapes, level_start_index, sampling_loc
 
 def _stream_and_guard(t):
     dev = t.device
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    stream = _vah.raw_stream(dev)
     return stream, (torch.cuda.device(dev) if torch.cuda.current_device() != dev.index else None)
 
 

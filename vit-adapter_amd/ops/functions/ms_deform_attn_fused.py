@@ -108,7 +108,7 @@ class MSDeformAttnFusedFunction(Function):
                     value.data_ptr(), _DT[value.dtype], offsets.data_ptr(), logits.data_ptr(), _DT[offsets.dtype],
                     ref.data_ptr(), win.perm.data_ptr(), win.group_off.data_ptr(), win.group_win.data_ptr(),
                     win.ngroups, win.max_win_px, win.H, win.W, win.start, N, S, M, D, Lq, P, out.data_ptr(),
-                    torch.cuda.current_stream(value.device).cuda_stream)
+                    _vah.raw_stream(value.device))
             _vah.check(rc, 'vah_msda_fused_forward_win')
             ctx.save_for_backward(value, spatial_shapes, level_start_index, offsets, logits, ref)
             ctx.tiled = tiled_backward(L, P)
@@ -118,7 +118,7 @@ class MSDeformAttnFusedFunction(Function):
                 value.data_ptr(), _DT[value.dtype], spatial_shapes.data_ptr(),
                 level_start_index.data_ptr(), offsets.data_ptr(), logits.data_ptr(),
                 _DT[offsets.dtype], ref.data_ptr(), ref.shape[1], N, S, M, D, L, Lq, P,
-                out.data_ptr(), torch.cuda.current_stream(value.device).cuda_stream)
+                out.data_ptr(), _vah.raw_stream(value.device))
         _vah.check(rc, 'vah_msda_fused_forward')
         ctx.save_for_backward(value, spatial_shapes, level_start_index, offsets, logits, ref)
         ctx.tiled = tiled_backward(L, P)
@@ -146,7 +146,7 @@ class MSDeformAttnFusedFunction(Function):
                         offsets.data_ptr(), logits.data_ptr(), _DT[offsets.dtype], ref.data_ptr(),
                         ref.shape[1], grad_output.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
                         _DT[value.dtype], d_off.data_ptr(), d_logit.data_ptr(), sh_host, lsi_host,
-                        ws.data_ptr(), ws_bytes, torch.cuda.current_stream(value.device).cuda_stream)
+                        ws.data_ptr(), ws_bytes, _vah.raw_stream(value.device))
                 _vah.check(rc, 'vah_msda_fused_backward_tiled')
                 return grad_value, None, None, d_off, d_logit, None
         # fallback: one float atomic per sample, corner and channel into a zeroed fp32 grad_value
@@ -156,6 +156,6 @@ class MSDeformAttnFusedFunction(Function):
                 value.data_ptr(), _DT[value.dtype], shapes.data_ptr(), lsi.data_ptr(),
                 offsets.data_ptr(), logits.data_ptr(), _DT[offsets.dtype], ref.data_ptr(),
                 ref.shape[1], grad_output.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
-                d_off.data_ptr(), d_logit.data_ptr(), torch.cuda.current_stream(value.device).cuda_stream)
+                d_off.data_ptr(), d_logit.data_ptr(), _vah.raw_stream(value.device))
         _vah.check(rc, 'vah_msda_fused_backward')
         return grad_value.to(value.dtype), None, None, d_off, d_logit, None

@@ -12,7 +12,7 @@ _FWD_TAPS = [(dy - 1, dx - 1) for dy in range(3) for dx in range(3)]
 
 
 def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return _vah.raw_stream(t.device)
 
 
 def _taps(call, x, w, taps, S, out, ny, nx, OS, oy0, ox0):

@@ -20,7 +20,7 @@ for _k in os.environ.get('VAH_FUSED_DISABLE', '').split(','):      # e.g. VAH_FU
 
 
 def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return _vah.raw_stream(t.device)
 
 
 def _scratch(K, device):

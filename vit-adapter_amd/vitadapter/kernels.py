@@ -10,7 +10,7 @@ import _vah  # noqa: F401  (hard requirement: raises ImportError when the .so is
 
 
 def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return _vah.raw_stream(t.device)
 
 
 def _attention_math(qkv, scale, dropout_p=0.):

@@ -15,7 +15,7 @@ from . import conv, fused
 
 
 def _stream(t):
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return _vah.raw_stream(t.device)
 
 
 def image_to_nhwc16(x):
