@@ -24,6 +24,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <sstream>
 #include <string>
@@ -54,10 +55,14 @@ struct Choice {
     bool resolved = false;   // algo valid (an entry loaded from text is resolved on first use)
 };
 
+struct Problem;
 struct State {
     std::mutex mu;
     hipblasLtHandle_t handle = nullptr;
     std::map<Key, Choice> table;
+    // descriptor sets kept per problem: creating and destroying one matmul descriptor and three layouts on every
+    // call was a measurable part of the ~20 us of host time a GEMM launch costs (~300 launches per training step)
+    std::map<Key, std::shared_ptr<Problem>> problems;
     int mode = 1;            // 0: first heuristic answer, 1: time the heuristic candidates, 2: time all
     int candidates = 32;
 };
@@ -456,6 +461,7 @@ static int gemm_impl(const char *fn, int trans_a, int trans_b, int64_t M, int64_
         if (split < 1 || K % split || make_problem(c, p, split) != HIPBLAS_STATUS_SUCCESS ||
             partial_bytes(c.k, split) >= c.ws_bytes || !resolve(S, c, p, it->second)) {
             S.table.erase(it);
+            S.problems.erase(c.k);
             it = S.table.end();
         }
     }
@@ -467,9 +473,18 @@ static int gemm_impl(const char *fn, int trans_a, int trans_b, int64_t M, int64_
                         (long long)M, (long long)N, (long long)K, trans_a, trans_b, d_is_f32, epilogue, status_name(s));
         it = S.table.emplace(c.k, ch).first;
     }
-    Problem p;
-    s = make_problem(c, p, it->second.split);
-    if (s != HIPBLAS_STATUS_SUCCESS) return fail(VAH_E_UNSUPPORTED, "%s: descriptor: %s", fn, status_name(s));
+    std::shared_ptr<Problem> &pp = S.problems[c.k];
+    if (!pp) {
+        pp = std::make_shared<Problem>();
+        s = make_problem(c, *pp, it->second.split);
+        if (s != HIPBLAS_STATUS_SUCCESS) {
+            S.problems.erase(c.k);
+            return fail(VAH_E_UNSUPPORTED, "%s: descriptor: %s", fn, status_name(s));
+        }
+    } else if (c.bias) {                    // the cached descriptor carries the previous call's bias pointer
+        hipblasLtMatmulDescSetAttribute(pp->desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &c.bias, sizeof(c.bias));
+    }
+    Problem &p = *pp;
     s = run(S, c, p, it->second.algo, it->second.workspace, it->second.split);
     if (s != HIPBLAS_STATUS_SUCCESS) return fail(VAH_E_UNSUPPORTED, "%s: hipblasLtMatmul: %s", fn, status_name(s));
     return check_launch(fn);
@@ -517,6 +532,7 @@ int vah_gemm_table_load(const char *text) {
     if (!text) return fail(VAH_E_NULL, "vah_gemm_table_load: null text");
     State &S = state();
     std::lock_guard<std::mutex> lock(S.mu);
+    S.problems.clear();             // their split may change with the loaded choices
     std::istringstream is(text);
     std::string line;
     int n = 0;
