@@ -12,12 +12,13 @@ MSDeformAttn core runs on bf16 values / offsets / logits with fp32 accumulation,
 bf16 MFMA tiles) -> loss = sum_k mean(f_k) -> backward (+ gradient all-reduce) -> fused AdamW
 update.  Inputs are resident in HBM before the timed region.
 
-One GPU (default `--hip-graph auto`): after the warm-up ONE step is captured into a HIP graph and the timed region is
-K replays of it - every kernel of the step, 0.3 ms of host time instead of 24-28 ms (the eager loop is host-bound on the
-slower-CPU boxes of the pool: 69.3 img/s there against 72.5-72.8 on the others and 73.7 replayed).  HIP events cannot be
-read back from inside a graph, so the per-kernel rows below are taken from K more EAGER steps of the same process right
-after the timed region (`config.hip_graph`, `config.kernel_rows`).  `--hip-graph off` (and every N > 1 run: DDP's
-buckets are not captured) times the eager loop with the events inside the timed region.
+One GPU (default `--hip-graph auto`): after the warm-up ONE step is captured into a HIP graph, three eager steps and
+three replays are timed (still warm-up), and the timed region runs the faster form: K replays (0.3 ms of host time per
+step) where the host is the longer pole - slow-CPU boxes, the 24-block presets - or the eager loop where the GPU is (it
+overlaps the weight-gradient GEMMs on a side stream, a captured graph does not).  HIP events cannot be read back from
+inside a graph, so after a replayed region the per-kernel rows are taken from K more EAGER steps of the same process
+(`config.hip_graph`, `config.hip_graph_probe`, `config.kernel_rows`).  `--hip-graph off` (and every N > 1 run: DDP's
+buckets are not captured) always times the eager loop with the events inside the timed region.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   "roofline":     the MSDA entry point with the largest total time in the timed region: bytes the
@@ -60,10 +61,11 @@ def parse():
     ap.add_argument('--size', type=int, nargs=2, default=[1024, 1024], metavar=('H', 'W'))
     ap.add_argument('--hip-graph', default='auto', choices=['auto', 'on', 'off'],
                     help='single GPU: capture one whole step (zero_grad, forward, backward, AdamW) into a HIP graph after the '
-                         'warm-up and time K replays of it (0.3 ms of host time per step instead of 24-28 ms); the per-kernel '
+                         'warm-up and time K replays of it (0.3 ms of host time per step instead of 20-70 ms); the per-kernel '
                          'rows then come from K more EAGER steps right after the timed region, because HIP events cannot be '
-                         'read back from inside a graph.  auto: on for one GPU (eager if the capture fails), off for N > 1 '
-                         '(DDP buckets are not captured); off: the eager loop with the events inside the timed region')
+                         'read back from inside a graph.  auto: one GPU AND the eager loop measured host-bound during the '
+                         'warm-up (eager if the capture fails); never for N > 1 (DDP buckets are not captured); off: always '
+                         'the eager loop with the events inside the timed region')
     ap.add_argument('--no-checkpoint', action='store_true',
                     help='presets with with_cp=True (the large models: the reference recomputes activations to fit 32 GB '
                          'cards): keep the activations instead - 288 GB of HBM holds them, same arithmetic')
@@ -399,6 +401,7 @@ def main():
         torch.cuda.synchronize()
 
     graph = None
+    probe = None
     if use_graph:
         # warm-up on a side stream (allocator pools, GEMM algorithm choices), then one captured step
         side = torch.cuda.Stream()
@@ -408,7 +411,22 @@ def main():
                 step()
         torch.cuda.current_stream().wait_stream(side)
         fence()
+
+        def wall(fn, n=3):
+            torch.cuda.synchronize()
+            p0 = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - p0) / n
+
         try:
+            # auto: which loop is faster HERE is measured, three steps each, still inside the warm-up.  Replay wins where
+            # the host is the longer pole (slow-CPU boxes, the 24-block presets); the eager loop wins where the GPU is
+            # (it overlaps the weight-gradient GEMMs on a side stream, which a captured graph does not) and keeps the
+            # HIP events inside the timed region.  The eager probe runs BEFORE the capture: replaying a graph after
+            # eager steps have released tensors it captured (gradients, bf16 weight copies) is not safe.
+            eager_ms = 1e3 * wall(step) if args.hip_graph == 'auto' else None
             # the parameters' AccumulateGrad nodes were made on the warm-up stream; the capture stream differs by design
             if hasattr(torch.autograd.graph, 'set_warn_on_accumulate_grad_stream_mismatch'):
                 torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
@@ -417,6 +435,10 @@ def main():
             with torch.cuda.graph(graph):
                 graph_loss = step()
             fence()
+            if eager_ms is not None:
+                probe = {'eager_ms': round(eager_ms, 3), 'graph_ms': round(1e3 * wall(graph.replay), 3)}
+                if probe['eager_ms'] <= probe['graph_ms']:
+                    graph, use_graph = None, False          # no replay from here on
         except Exception as exc:                       # noqa: BLE001 - any capture failure: the eager loop below
             if args.hip_graph == 'on':
                 raise
@@ -488,7 +510,7 @@ def main():
                                        + (', activations kept (with_cp off)' if args.no_checkpoint else '')),
                        'global_batch': world * args.batch, 'params_M': round(n_params / 1e6, 2),
                        'parallelism': 'dp%d' % world,
-                       'hip_graph': use_graph,
+                       'hip_graph': use_graph, 'hip_graph_probe': probe,
                        'kernel_rows': ('HIP events over %d eager steps right after the timed region (events cannot be read '
                                        'back from inside a graph)' % args.steps) if use_graph else 'HIP events inside the timed region',
                        'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
