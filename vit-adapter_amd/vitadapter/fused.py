@@ -356,6 +356,8 @@ class _SideStream:
 
     def begin_epoch(self):
         self.uses = {}
+        for idx in list(self.pending):      # a backward pass that died before its callback: join now, never leave a fork open
+            self.join(idx)
 
     def note(self, param):
         """Called by a forward that uses ``param`` once; returns the token its backward hands to ``may_defer``.
