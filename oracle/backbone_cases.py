@@ -98,6 +98,38 @@ BEIT_CASES = {
 }
 
 
+# detection flavour (mmdet_custom/models/backbones/beit_adapter.py): no class token, windowed blocks (grid padded
+# BEFORE the projection) and global blocks whose window is the whole grid, per-block (2w-1)^2 bias tables
+BEIT_DET_CASES = {
+    # 4 x 4 token grid: windows of 2 (no padding), global blocks with window 4
+    'beit_det_64': dict(cfg=dict(img_size=64, patch_size=16, embed_dim=64, depth=4, num_heads=2, mlp_ratio=4,
+                                 qkv_bias=True, use_abs_pos_emb=False, use_rel_pos_bias=True, init_values=1e-6,
+                                 drop_path_rate=0., conv_inplane=16, n_points=4, deform_num_heads=2,
+                                 cffn_ratio=0.25, deform_ratio=1.0, with_cp=False, version='new',
+                                 window_attn=[True, False, True, False], window_size=[2, 4, 2, 4],
+                                 interaction_indexes=[[0, 0], [1, 1], [2, 2], [3, 3]]),
+                        hw=(64, 64), batch=2, modes=('eval', 'train')),
+    # 6 x 6 token grid: windows of 4 (padded to 8 x 8: padded tokens carry q_bias / v_bias), global window 6,
+    # absolute position embedding resized from a 2 x 2 pretraining grid, version 'old' (a map per interaction)
+    'beit_det_96': dict(cfg=dict(img_size=96, patch_size=16, embed_dim=64, depth=4, num_heads=1, mlp_ratio=2,
+                                 qkv_bias=True, use_abs_pos_emb=False, use_rel_pos_bias=True, init_values=1e-6,
+                                 drop_path_rate=0., conv_inplane=16, n_points=4, deform_num_heads=1,
+                                 cffn_ratio=0.25, deform_ratio=0.5, with_cp=False, version='old',
+                                 window_attn=[True, True, False, True], window_size=[4, 4, 6, 4],
+                                 interaction_indexes=[[0, 0], [1, 1], [2, 2], [3, 3]]),
+                        hw=(96, 96), batch=1, modes=('train',)),
+}
+
+
+def beit_det_input(name):
+    c = BEIT_DET_CASES[name]
+    return seeded.randn('beit_det/%s/x' % name, (c['batch'], 3) + tuple(c['hw']), 13)
+
+
+def beit_det_gouts(name, shapes):
+    return [seeded.randn('beit_det/%s/g%d' % (name, k), s, 13) for k, s in enumerate(shapes)]
+
+
 def beit_input(name):
     c = BEIT_CASES[name]
     return seeded.randn('beit/%s/x' % name, (c['batch'], 3) + tuple(c['hw']), 13)

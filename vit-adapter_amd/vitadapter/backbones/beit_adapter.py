@@ -114,9 +114,17 @@ class BEiTAdapter(BEiT):
         return [self.norm1(c1), self.norm2(c2), self.norm3(c3), self.norm4(c4)]
 
 
-def register_beit_adapter(registry=None, name='BEiTAdapter', force=True):
-    """Register into mmseg's BACKBONES under the reference's name."""
+def register_beit_adapter(registry=None, name='BEiTAdapter', force=True, flavour='seg'):
+    """Register into mmseg's (flavour 'seg') or mmdet's ('det': the windowed trunk without class token,
+    backbones/beit_det.py) BACKBONES under the reference's name."""
+    if flavour == 'det':
+        from .beit_det import BEiTAdapter as cls
+    else:
+        cls = BEiTAdapter
     if registry is None:
-        from mmseg.models.builder import BACKBONES as registry
-    registry.register_module(name=name, force=force, module=BEiTAdapter)
-    return BEiTAdapter
+        if flavour == 'det':
+            from mmdet.models.builder import BACKBONES as registry
+        else:
+            from mmseg.models.builder import BACKBONES as registry
+    registry.register_module(name=name, force=force, module=cls)
+    return cls
