@@ -55,7 +55,7 @@ MFMA_PEAK = 2.5e15    # flop/s, dense bf16 MFMA (same guide; the 5 PF headline i
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--preset', default='base_det', help='vitadapter preset (base_det = BASELINE configs[2])')
     ap.add_argument('--size', type=int, nargs=2, default=[1024, 1024], metavar=('H', 'W'))
