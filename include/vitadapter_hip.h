@@ -141,29 +141,33 @@ int vah_msda_fused_forward_win(const void *value, int value_dtype, const void *o
 /* ------------------------------------------------------------------------------------
  * TILED BACKWARD: grad_value without atomics and without a zero-fill, for ANY sampling locations
  * (csrc/msda_tile.hip; replaces the scatter of ms_deform_im2col_cuda.cuh:87-159 as called from
- * :301-403).  One binning pass puts every (n, q, m, level) row into the lists of the 8x4-pixel tiles of the
- * value map its samples touch (fixed list capacity per level; a list that overflows is replaced by a walk over
- * all queries: slow, exact); then one single-wave workgroup per (n, head, tile) - several for the long lists of
- * coarse levels - sums its list on the matrix cores (weights [32 px x 64 entries] x grad_out rows [64 x 32 ch];
- * bf16 rows: v_mfma_f32_32x32x16_bf16 with the weights as bf16 hi + lo; fp32 rows: v_mfma_f32_32x32x2_f32) and
- * STORES the tile: every grad_value element is written exactly once, whatever it held on entry.
- * grad_loc / grad_attn (d_offsets / d_logits) come from the gather kernels (scatter switched off) or, for the
- * single-level bf16 call, from the tile pass itself (each sample is owned by the tile of its first corner).
- *   shapes_host / lsi_host : HOST copies of spatial_shapes / level_start_index (the grids and the
- *                            workspace are sized from them; the device copies are still passed for
- *                            the gather kernel).  Every level must be a window of [0, S).
+ * :301-403).  No argument is a host copy of device data: like the reference kernels (cuh:274-277) these read
+ * spatial_shapes / level_start_index on the device; grids and the workspace are sized from (N, S, M, L, Lq)
+ * alone, so a call makes no D2H read and can be captured in a HIP graph with fresh shape tensors.
+ * Kernels: (0) plan: level table, list counters zeroed; (1) binning: every (n, q, m, level) row into the lists of
+ * the 8x4-pixel tiles of the value map its samples touch (fixed list capacity per level; a list that overflows is
+ * replaced by a walk over all queries: slow, exact); (2) tile pass: persistent single-wave workgroups walk the
+ * (n, head, tile) lists and sum each on the matrix cores (grad_out rows^T [32 ch x 64 entries] x weights
+ * [64 entries x 32 px]; bf16 rows: v_mfma_f32_32x32x16_bf16 with the weights as bf16 hi + lo; fp32 rows:
+ * v_mfma_f32_32x32x2_f32) and STORE the tile: every grad_value element is written exactly once, whatever it held
+ * on entry.  If the levels do not tile [0, S) exactly (gaps, overlaps, a level outside the value rows) grad_value
+ * is zero-filled by the plan kernel and the tile pass adds with atomics instead (the reference's zeros + atomics
+ * semantics); a level outside the value rows contributes nothing.
+ * grad_loc / grad_attn (d_offsets / d_logits): fp32 values - the gather kernels (scatter switched off) in front;
+ * bf16 values - the tile pass itself (each sample is owned by the tile of its first in-map corner; corner dot
+ * products against the tile's 10x6-pixel value window on the matrix cores) + a softmax-backward pass.
  *   ws / ws_bytes          : device workspace of at least vah_msda_tile_ws_bytes(...) bytes, 16-byte
- *                            aligned, contents arbitrary (list counters, entries, partial tiles, d(out)/d(p))
+ *                            aligned, contents arbitrary (plan, list counters, entries, partial tiles, d(out)/d(p))
  *   needs D == 32, P == 4, 1 <= L <= 4 (VAH_E_UNSUPPORTED otherwise: use the functions above)
- * vah_msda_fused_backward_tiled: grad_value_dtype 0 = fp32, 1 = bf16 (bf16 values only).
+ * vah_msda_fused_backward_tiled: grad_value_dtype 0 = fp32, 1 = bf16 (bf16 values only); grad_param_dtype: type of
+ * d_offsets / d_logits, = param_dtype or bf16 for fp32 offsets / logits (bf16 values only: the module keeps the
+ * sampling offsets in fp32 under autocast and hands bf16 gradients to its Linear layers).
  * ------------------------------------------------------------------------------------ */
-int64_t vah_msda_tile_ws_bytes(int64_t N, int64_t S, int64_t M, int64_t L, int64_t Lq, int64_t P,
-                               const int64_t *shapes_host, const int64_t *lsi_host);     /* < 0: not supported */
+int64_t vah_msda_tile_ws_bytes(int64_t N, int64_t S, int64_t M, int64_t L, int64_t Lq, int64_t P);     /* < 0: not supported */
 int vah_msda_backward_tiled_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
                                 const float *loc, const float *attn, const float *grad_out, int64_t N,
                                 int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P,
-                                float *grad_value, float *grad_loc, float *grad_attn,
-                                const int64_t *shapes_host, const int64_t *lsi_host, void *ws,
+                                float *grad_value, float *grad_loc, float *grad_attn, void *ws,
                                 int64_t ws_bytes, void *stream);
 int vah_msda_fused_backward_tiled(const void *value, int value_dtype, const int64_t *shapes,
                                   const int64_t *lsi, const void *offsets, const void *logits,
@@ -171,8 +175,7 @@ int vah_msda_fused_backward_tiled(const void *value, int value_dtype, const int6
                                   const void *grad_out, int64_t N, int64_t S, int64_t M, int64_t D,
                                   int64_t L, int64_t Lq, int64_t P, void *grad_value,
                                   int grad_value_dtype, void *d_offsets, void *d_logits,
-                                  const int64_t *shapes_host, const int64_t *lsi_host, void *ws,
-                                  int64_t ws_bytes, void *stream);
+                                  int grad_param_dtype, void *ws, int64_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Softmax attention of the ViT blocks, bf16, head_dim 64  

@@ -144,3 +144,41 @@ def float_shapes(module):
     buffers such as relative_position_index are structural and keep the module's own values."""
     return {k: tuple(v.shape) for k, v in module.state_dict().items()
             if v.is_floating_point() or k.endswith('num_batches_tracked')}
+
+
+# ---- full-size headline workloads (SURVEY 8c G5 "checksums for 512^2 batch 2"; VERDICT r2 item 1) -----------------
+# BASELINE configs[1] (ViT-Adapter-T, 512 x 512, batch 2) and configs[2] (ViT-Adapter-B det flavour, 1024 x 1024, one
+# image: the per-GPU batch of 2 is two independent images, SyncBN statistics aside).  Train mode, drop_path 0 (no RNG in
+# the graph), seeded weights.  The fixture holds DIGESTS: per output the fp64 sum + 4096 sampled elements, per parameter
+# gradient seeded.digest + its L2 norm (tools/gen_golden_fullsize.py, from the reference's own classes).
+FULLSIZE_CASES = {
+    'tiny_seg_512': dict(cfg=dict(flavour='seg', patch_size=16, embed_dim=192, depth=12, num_heads=3, mlp_ratio=4,
+                                  drop_path_rate=0., conv_inplane=64, n_points=4, deform_num_heads=6, cffn_ratio=0.25,
+                                  deform_ratio=1.0, interaction_indexes=[[0, 2], [3, 5], [6, 8], [9, 11]],
+                                  window_attn=[False] * 12, window_size=[None] * 12),
+                         hw=(512, 512), batch=2),
+    'base_det_1024': dict(cfg=dict(flavour='det', patch_size=16, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4,
+                                   drop_path_rate=0., conv_inplane=64, n_points=4, deform_num_heads=12, cffn_ratio=0.25,
+                                   deform_ratio=0.5, interaction_indexes=[[0, 2], [3, 5], [6, 8], [9, 11]],
+                                   window_attn=[True, True, False] * 4, window_size=[14, 14, None] * 4),
+                          hw=(1024, 1024), batch=1),
+}
+FULLSIZE_SAMPLES = 4096
+
+
+def fullsize_input(name):
+    c = FULLSIZE_CASES[name]
+    return seeded.randn('fullsize/%s/x' % name, (c['batch'], 3) + tuple(c['hw']), 21)
+
+
+def fullsize_gouts(name, shapes):
+    """Seeded output gradients, scaled so that every level contributes a gradient of similar size."""
+    return [seeded.randn('fullsize/%s/g%d' % (name, k), s, 21) for k, s in enumerate(shapes)]
+
+
+def fullsize_positions(key, numel):
+    """FULLSIZE_SAMPLES seeded flat positions into a tensor of ``numel`` elements."""
+    g = torch.Generator(device='cpu')
+    import zlib
+    g.manual_seed(zlib.crc32(('pos/' + key).encode()) % (2 ** 31 - 1))
+    return torch.randint(0, numel, (FULLSIZE_SAMPLES,), generator=g)

@@ -105,14 +105,14 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
     grad_loc = torch.empty_like(sampling_loc)
     grad_attn = torch.empty_like(attn_weight)
     fn = _vah.lib.vah_msda_backward_f32 if value.dtype == torch.float32 else _vah.lib.vah_msda_backward_f64
-    # atomic-free tiled grad_value (csrc/msda_tile.hip): fp32, D == 32, P == 4, L <= 4, levels inside [0, S)
+    # atomic-free tiled grad_value (csrc/msda_tile.hip): fp32, D == 32, P == 4, L <= 4.  Grid and workspace follow
+    # from the tensor SHAPES alone; the level geometry is read on the device (no D2H read, no host cache)
     tiled = None
     if (value.dtype == torch.float32 and D == 32 and P == 4 and 1 <= L <= 4 and N * Lq * M > 0
             and os.environ.get('VAH_MSDA_TILED', '1') != '0'):
-        sh_host, lsi_host, _ = _vah.host_geometry(spatial_shapes, level_start_index)
-        ws_bytes = _vah.lib.vah_msda_tile_ws_bytes(N, S, M, L, Lq, P, sh_host, lsi_host)
+        ws_bytes = _vah.lib.vah_msda_tile_ws_bytes(N, S, M, L, Lq, P)
         if ws_bytes >= 0:
-            tiled = (sh_host, lsi_host, torch.empty(ws_bytes, dtype=torch.uint8, device=value.device), ws_bytes)
+            tiled = (torch.empty(ws_bytes, dtype=torch.uint8, device=value.device), ws_bytes)
     # the tile pass stores every element of grad_value; the scatter kernels accumulate into zeros
     grad_value = torch.empty_like(value) if tiled else torch.zeros_like(value)
     stream, guard = _stream_and_guard(value)
@@ -124,7 +124,7 @@ def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_l
                 value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                 sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),
                 N, S, M, D, L, Lq, P, grad_value.data_ptr(), grad_loc.data_ptr(), grad_attn.data_ptr(),
-                tiled[0], tiled[1], tiled[2].data_ptr(), tiled[3], stream)
+                tiled[0].data_ptr(), tiled[1], stream)
         else:
             rc = fn(value.data_ptr(), spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                     sampling_loc.data_ptr(), attn_weight.data_ptr(), grad_output.data_ptr(),

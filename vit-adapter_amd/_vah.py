@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
-ABI_VERSION = 34
+ABI_VERSION = 35
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -74,12 +74,12 @@ lib.vah_msda_fused_backward.argtypes = [_p, _ci, _p, _p, _p, _p, _ci, _p, _i64, 
 lib.vah_msda_fused_backward.restype = ctypes.c_int
 lib.vah_msda_fused_forward_win.argtypes = [_p, _ci, _p, _p, _ci, _p, _p, _p, _p] + [_i64] * 11 + [_p, _p]
 lib.vah_msda_fused_forward_win.restype = ctypes.c_int
-lib.vah_msda_tile_ws_bytes.argtypes = [_i64] * 6 + [_p, _p]
+lib.vah_msda_tile_ws_bytes.argtypes = [_i64] * 6
 lib.vah_msda_tile_ws_bytes.restype = _i64
-lib.vah_msda_backward_tiled_f32.argtypes = [_p] * 6 + [_i64] * 7 + [_p] * 3 + [_p, _p, _p, _i64, _p]
+lib.vah_msda_backward_tiled_f32.argtypes = [_p] * 6 + [_i64] * 7 + [_p] * 3 + [_p, _i64, _p]
 lib.vah_msda_backward_tiled_f32.restype = ctypes.c_int
 lib.vah_msda_fused_backward_tiled.argtypes = ([_p, _ci, _p, _p, _p, _p, _ci, _p, _i64, _p] + [_i64] * 7
-                                              + [_p, _ci, _p, _p, _p, _p, _p, _i64, _p])
+                                              + [_p, _ci, _p, _p, _ci, _p, _i64, _p])
 lib.vah_msda_fused_backward_tiled.restype = ctypes.c_int
 _f = ctypes.c_float
 lib.vah_layernorm_fwd_f32_bf16.argtypes = [_p, _p, _p, _i64, _i64, _f, _p, _p, _p, _p]

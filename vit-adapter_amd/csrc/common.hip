@@ -103,7 +103,7 @@ LaunchScope::~LaunchScope() {
 
 extern "C" {
 
-int vah_abi_version(void) { return 34; }
+int vah_abi_version(void) { return 35; }
 
 const char *vah_last_error(void) { return vah::g_err; }
 

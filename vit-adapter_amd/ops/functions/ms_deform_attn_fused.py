@@ -131,13 +131,14 @@ class MSDeformAttnFusedFunction(Function):
         N, S, M, D = value.shape
         _, Lq, _, L, P, _ = offsets.shape
         grad_output = grad_output.contiguous().to(value.dtype)
-        d_off = torch.empty_like(offsets)
-        d_logit = torch.empty_like(logits)
         if ctx.tiled:
-            # atomic-free tile pass (csrc/msda_tile.hip): grad_value is STORED, in the value's dtype
-            sh_host, lsi_host, _ = _vah.host_geometry(shapes, lsi)
-            ws_bytes = _vah.lib.vah_msda_tile_ws_bytes(N, S, M, L, Lq, P, sh_host, lsi_host)
+            # atomic-free tile pass (csrc/msda_tile.hip): grad_value is STORED, in the value's dtype.  Nothing about the
+            # level geometry is read back to the host: grid and workspace follow from the tensor shapes.
+            ws_bytes = _vah.lib.vah_msda_tile_ws_bytes(N, S, M, L, Lq, P)
             if ws_bytes >= 0:
+                gdt = offsets.dtype
+                d_off = torch.empty(offsets.shape, dtype=gdt, device=offsets.device)
+                d_logit = torch.empty(logits.shape, dtype=gdt, device=logits.device)
                 grad_value = torch.empty_like(value)
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
                 with _vah.on(value.device):
@@ -145,10 +146,12 @@ class MSDeformAttnFusedFunction(Function):
                         value.data_ptr(), _DT[value.dtype], shapes.data_ptr(), lsi.data_ptr(),
                         offsets.data_ptr(), logits.data_ptr(), _DT[offsets.dtype], ref.data_ptr(),
                         ref.shape[1], grad_output.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(),
-                        _DT[value.dtype], d_off.data_ptr(), d_logit.data_ptr(), sh_host, lsi_host,
+                        _DT[value.dtype], d_off.data_ptr(), d_logit.data_ptr(), _DT[gdt],
                         ws.data_ptr(), ws_bytes, _vah.raw_stream(value.device))
                 _vah.check(rc, 'vah_msda_fused_backward_tiled')
                 return grad_value, None, None, d_off, d_logit, None
+        d_off = torch.empty_like(offsets)
+        d_logit = torch.empty_like(logits)
         # fallback: one float atomic per sample, corner and channel into a zeroed fp32 grad_value
         grad_value = torch.zeros(value.shape, dtype=torch.float32, device=value.device)
         with _vah.on(value.device):
