@@ -449,6 +449,9 @@ int vah_gemm_bf16_fin(int trans_a, int trans_b, int64_t M, int64_t N, int64_t K,
                       int64_t workspace_bytes, const float *fin_part, int64_t fin_nparts, int64_t fin_C,
                       float *fin_out, void *stream);   /* + fin_out[c] = sum_p fin_part[p * fin_C + c] */
 int64_t vah_gemm_library_version(void);                /* hipBLASLt build the algorithm indices belong to */
+/* Tuning candidates dropped so far because the 64 x 64 corner of their result differed from the corner the heuristic's
+ * first answer computes for the same operands (an algorithm that runs without an error status may still be wrong). */
+int64_t vah_gemm_rejected_candidates(void);
 int64_t vah_gemm_table_dump(char *buf, int64_t cap);   /* returns the size needed (incl. NUL) */
 int vah_gemm_table_load(const char *text);             /* returns the number of entries, < 0 on error */
 /* y = x + s[b] * gamma[c] * z   (x, y fp32 (batch, rows_per_batch, C); z bf16; gamma (C) or NULL;

@@ -23,9 +23,28 @@ CASES = {
 }
 
 
+# detection flavour (detection/mmcv_custom/checkpoint.py:379-445): per-block tables WITHOUT class-token rows in the model
+# ((2 w - 1)^2 rows for a window of w), 3 more rows in the checkpoint that the loader always drops.  Equal-size branch
+# only (the other one needs scipy's interp2d, gone from this image): 4 x 4 token grid, windows of 2 and the global 4.
+DET_CASES = {
+    'det_tables_equal_size': dict(
+        model=dict(img_size=64, use_abs_pos_emb=False, use_rel_pos_bias=True, window_attn=[True, False],
+                   window_size=[2, 4], **_SMALL),
+        check=['blocks.0.attn.relative_position_bias_table', 'blocks.1.attn.relative_position_bias_table',
+               'blocks.1.attn.proj.weight']),
+}
+
+
 def checkpoint(name):
     """The dict torch.save()d for case ``name``."""
     C = _SMALL['embed_dim']
+    if name == 'det_tables_equal_size':
+        sd = {
+            'blocks.0.attn.relative_position_bias_table': seeded.randn('ckpt/det/t0', (3 * 3 + 3, _SMALL['num_heads']), 33),
+            'blocks.1.attn.relative_position_bias_table': seeded.randn('ckpt/det/t1', (7 * 7 + 3, _SMALL['num_heads']), 33),
+            'blocks.1.attn.proj.weight': seeded.randn('ckpt/det/proj', (C, C), 33),
+        }
+        return {'model': sd}
     if name == 'pos_embed_resize':
         sd = {
             'pos_embed': seeded.randn('ckpt/pos_embed', (1, 4 * 4 + 1, C), 31),

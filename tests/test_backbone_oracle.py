@@ -119,3 +119,23 @@ def test_oracle_parts_match_reference(gold):
         g = torch.autograd.grad((o * bc.part_gout(bname, o.shape)).sum(), [t])
         _close(o, gold['part_%s_out' % bname], 1e-5, bname)
         _close(g[0], gold['part_%s_gx' % bname], 2e-5, bname + ' gx')
+
+
+def test_oracle_backbone_matches_reference_at_full_size(golden_dir):
+    """BASELINE configs[1] at its real size (ViT-Adapter-T, 512 x 512, batch 2, train mode): the oracle restatement
+    against the digests the reference's own class produced (tools/gen_golden_fullsize.py) - 4096 sampled elements, sum
+    and L2 norm of every pyramid level.  (configs[2] at 1024 x 1024 takes a minute on the CPU: GPU tier only.)"""
+    gold = np.load(os.path.join(golden_dir, 'backbone_fullsize.npz'))
+    name = 'tiny_seg_512'
+    case = bc.FULLSIZE_CASES[name]
+    meta = json.loads(str(gold['meta']))[name]['state_dict']
+    sd = seeded.seeded_state_dict({k: tuple(s) for k, s in meta.items()}, 5)
+    with torch.no_grad():
+        outs = ref.vit_adapter_forward(sd, bc.fullsize_input(name), ref.Cfg(**case['cfg']), training=True)
+    for k, o in enumerate(outs):
+        tag = '%s_f%d' % (name, k + 1)
+        flat = o.reshape(-1)
+        got = flat[bc.fullsize_positions(tag, flat.numel())].double().numpy()
+        s_sum, s_max, s_l2 = gold[tag + '_sum']
+        assert np.abs(got - gold[tag + '_samples']).max() <= 2e-4 * max(1.0, s_max), tag
+        assert abs(float(o.double().sum()) - s_sum) <= 2e-4 * s_l2 and abs(float(o.double().pow(2).sum().sqrt()) - s_l2) <= 2e-4 * s_l2, tag

@@ -174,6 +174,44 @@ def test_empty_and_malformed_levels(MSDA):
     assert float(gl.abs().max()) == 0 and float(ga.abs().max()) == 0
 
 
+@pytest.mark.parametrize('geometry', ['trailing_rows', 'gap_between_levels', 'overlapping_levels'])
+def test_levels_that_do_not_tile_the_value_rows(MSDA, geometry):
+    """the tile pass STORES grad_value, so value rows no level covers must come back as zeros (the reference
+    starts from zeros, ms_deform_attn_cuda.cu:121) and rows two levels share must receive both contributions (the
+    reference adds atomically, cuh:87-159).  The plan kernel detects such geometry on the device, zero-fills and the
+    tile pass adds instead of storing.  Against the C oracle (which follows level_start_index literally); D = 32,
+    P = 4: the tiled path.  Also the fused bf16 core (grad_value only, against the plain fp32 path)."""
+    torch.manual_seed(7)
+    N, M, D, P, Lq = 2, 3, 32, 4, 50
+    shapes = [(6, 4), (3, 2)]
+    if geometry == 'trailing_rows':
+        lsi, S = [0, 24], 40                    # rows 30..39 belong to no level
+    elif geometry == 'gap_between_levels':
+        lsi, S = [0, 30], 36                    # rows 24..29 belong to no level
+    else:
+        lsi, S = [0, 20], 26                    # rows 20..23 belong to both levels
+    L = len(shapes)
+    hw = torch.tensor(shapes, dtype=torch.long)
+    li = torch.tensor(lsi, dtype=torch.long)
+    value = torch.randn(N, S, M, D)
+    loc = torch.rand(N, Lq, M, L, P, 2)
+    attn = torch.softmax(torch.randn(N, Lq, M, L * P), -1).view(N, Lq, M, L, P)
+    gout = torch.randn(N, Lq, M * D)
+    v, s_, i_, l_, a_, g_ = _dev((value, hw, li, loc, attn, gout))
+    out = MSDA.ms_deform_attn_forward(v, s_, i_, l_, a_, 64)
+    gv, gl, ga = MSDA.ms_deform_attn_backward(v, s_, i_, l_, a_, g_, 64)
+    torch.cuda.synchronize()
+    args = [value.numpy(), hw.numpy(), li.numpy(), loc.numpy(), attn.numpy()]
+    want = [oracle_msda.forward(*args)] + list(oracle_msda.backward(*args, gout.numpy()))
+    for nm, x, r in zip(('out', 'gv', 'gl', 'ga'), (out, gv, gl, ga), want):
+        _assert_close(x.cpu().numpy(), r, 1e-4, geometry + ':' + nm)
+    if geometry != 'overlapping_levels':
+        covered = torch.zeros(S, dtype=torch.bool)
+        for (h, w), st in zip(shapes, lsi):
+            covered[st:st + h * w] = True
+        assert float(gv.cpu()[:, ~covered].abs().max()) == 0.0
+
+
 def test_non_default_stream(MSDA):
     value, hw, lsi, loc, attn, gout = cases.msda_inputs('ext128_adapter',
                                                         **cases.PARITY_CASES['ext128_adapter'])

@@ -77,27 +77,76 @@ def test_backward_uses_the_copy_of_its_own_forward_gpu():
 
 
 def test_side_stream_deferral_rules():
-    """Weight gradients may stay on the side stream only when autograd will merely store them: leaf parameter without a
-    .grad, one use per forward epoch, no multi-rank process group (vitadapter/fused.py::_SideStream)."""
+    """Weight gradients may stay on the side stream only when autograd will merely store them.  The decision is taken at
+    BACKWARD time (vitadapter/fused.py::_SideStream.may_defer): parameter alive, leaf, without a .grad, no gradient of
+    this backward pass already deferred for it, no multi-rank process group."""
     import torch
     from vitadapter import fused
     side = fused._SideStream()
-    p = torch.nn.Parameter(torch.zeros(4, 4))
-    dev = torch.device('cuda', 0)
+    w = torch.nn.Parameter(torch.zeros(4, 4))
+    b = torch.nn.Parameter(torch.zeros(4))
+    cpu = torch.device('cpu')
     fused.BF16_COPIES.epoch = 1            # an open forward epoch
     try:
         side.begin_epoch()
-        tok = side.note(p)
-        assert tok is not None and tok[0] == 1
-        tok2 = side.note(p)                # second use in the same forward: autograd will add the two gradients
-        assert tok2 is tok and tok[0] == 2
-        assert not side.may_defer(tok, dev) if torch.cuda.is_available() else True
-        side.begin_epoch()
-        p.grad = torch.zeros_like(p)       # gradient accumulation across micro-batches
-        assert side.note(p) is None
-        p.grad = None
-        assert side.note(p.view(16)) is None          # not a leaf
-        assert side.may_defer(None, dev) is False
-        assert side.may_defer(side.note(p), torch.device('cpu')) is False
+        tok = side.note(w, b)
+        assert tok is not None and tok[0]() is w and tok[1]() is b
+        assert side.note(w.view(16), None) is None                   # not a leaf
+        assert side.may_defer(None, cpu) is False
+        assert side.may_defer(tok, cpu) is False                     # not a GPU tensor
+        if torch.cuda.is_available():
+            dev = torch.device('cuda', 0)
+            assert side.may_defer(tok, dev) is True                  # first gradient of the pass: deferred, parameters marked
+            assert side.may_defer(side.note(w, b), dev) is False     # a second node of the same weight in this pass: not again
+            side.begin_epoch()
+            w.grad = torch.zeros_like(w)                             # gradient accumulation across micro-batches / passes
+            assert side.may_defer(side.note(w, b), dev) is False
+            w.grad = None
+            assert side.may_defer(side.note(w, b), dev) is True
     finally:
         fused.BF16_COPIES.epoch = 0
+        side.deferred.clear()
+
+
+def _lin_grads(lin, holder, xs, retain=False, extra_use=False):
+    """Gradients of a fused Linear after (a) several forwards and ONE backward, (b) a second backward on a retained
+    graph, (c) a second use of the weight by a plain operator in the same graph."""
+    lin.zero_grad(set_to_none=True)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        total = 0
+        for x in xs:
+            with fused.forward_epoch(holder):
+                y = fused.linear(lin, x)
+            total = total + (y.float() ** 2).sum()
+            if extra_use:
+                total = total + torch.nn.functional.linear(x.float(), lin.weight.float()).sum()
+    total.backward(retain_graph=retain)
+    if retain:
+        total.backward()
+    torch.cuda.synchronize()
+    return lin.weight.grad.clone(), lin.bias.grad.clone()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['two_forwards_one_backward', 'retain_graph_double_backward', 'weight_used_by_another_op'])
+def test_side_stream_gradients_equal_main_stream_gradients(case):
+    """the weight-gradient GEMMs left on the side stream must never race with autograd's accumulation.  Same
+    graph with the overlap on and off (VAH_FUSED_DISABLE=wgrad_overlap): identical gradients, repeated so that a race
+    would have room to show."""
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(768, 768).cuda()
+    holder = torch.nn.ModuleList([lin])
+    n = 2 if case == 'two_forwards_one_backward' else 1
+    xs = [torch.randn(8192, 768, device='cuda') for _ in range(n)]
+    kw = dict(retain=case == 'retain_graph_double_backward', extra_use=case == 'weight_used_by_another_op')
+    old = fused.ENABLED['wgrad_overlap']
+    try:
+        fused.ENABLED['wgrad_overlap'] = False
+        want = _lin_grads(lin, holder, xs, **kw)
+        fused.ENABLED['wgrad_overlap'] = True
+        for _ in range(5):
+            got = _lin_grads(lin, holder, xs, **kw)
+            for g, w in zip(got, want):
+                assert torch.equal(g, w), case
+    finally:
+        fused.ENABLED['wgrad_overlap'] = old

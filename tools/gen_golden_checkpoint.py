@@ -33,6 +33,14 @@ import gen_golden as gg                                   # noqa: E402
 from oracle import checkpoint_cases as cc                 # noqa: E402
 
 
+def load_reference_loader_det():
+    path = os.path.join(gg.REF, 'detection', 'mmcv_custom', 'checkpoint.py')
+    spec = importlib.util.spec_from_file_location('ref_checkpoint_det', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def load_reference_loader():
     gg._mod('mmcv.fileio', FileClient=object, load=lambda *a, **k: None)
     gg._mod('mmcv.parallel', is_module_wrapper=lambda m: False)
@@ -64,6 +72,21 @@ def main():
             path = os.path.join(tmp, name + '.pth')
             torch.save(cc.checkpoint(name), path)
             ref.load_checkpoint(model, path, map_location='cpu', strict=False, logger=None)
+            sd = model.state_dict()
+            for k in case['check']:
+                g['%s/%s' % (name, k)] = sd[k].detach().numpy()
+        # detection flavour: the reference's det loader into the reference's det BEiT (windowed / global blocks)
+        gg.load_reference_backbone('det')
+        beit_det = importlib.import_module('ref_det.base.beit')
+        ref_det = load_reference_loader_det()
+        for name, case in cc.DET_CASES.items():
+            torch.manual_seed(0)
+            model = beit_det.BEiT(**case['model'])
+            for p in model.parameters():
+                torch.nn.init.constant_(p, 0.25)
+            path = os.path.join(tmp, name + '.pth')
+            torch.save(cc.checkpoint(name), path)
+            ref_det.load_checkpoint(model, path, map_location='cpu', strict=False, logger=None)
             sd = model.state_dict()
             for k in case['check']:
                 g['%s/%s' % (name, k)] = sd[k].detach().numpy()

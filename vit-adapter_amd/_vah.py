@@ -102,6 +102,8 @@ lib.vah_gemm_table_dump.restype = _i64
 lib.vah_gemm_table_load.argtypes = [ctypes.c_char_p]
 lib.vah_gemm_library_version.argtypes = []
 lib.vah_gemm_library_version.restype = _i64
+lib.vah_gemm_rejected_candidates.argtypes = []
+lib.vah_gemm_rejected_candidates.restype = _i64
 _tail_in = [_p, _int, _p, _int, _p, _int, _i64, _i64, _i64, _i64]
 lib.vah_bn_tail_ws_floats.argtypes = [_i64]
 lib.vah_bn_tail_ws_floats.restype = _i64
@@ -164,7 +166,7 @@ EXPORTS = (
     'vah_scale_residual_bwd', 'vah_dwconv3x3_tokens_bf16', 'vah_dwconv3x3_tokens_wgrad_bf16', 'vah_colsum_bf16', 'vah_colsum_f32',
     'vah_layernorm_dual_fwd', 'vah_layernorm_dual_bwd',
     'vah_residual_layernorm_fwd', 'vah_residual_layernorm_bwd',
-    'vah_gemm_set_tuning', 'vah_gemm_bf16', 'vah_gemm_bf16_fin', 'vah_colsum_bf16_partials', 'vah_gemm_table_dump', 'vah_gemm_table_load', 'vah_gemm_library_version',
+    'vah_gemm_set_tuning', 'vah_gemm_bf16', 'vah_gemm_bf16_fin', 'vah_colsum_bf16_partials', 'vah_gemm_table_dump', 'vah_gemm_table_load', 'vah_gemm_library_version', 'vah_gemm_rejected_candidates',
     'vah_bn_tail_ws_floats', 'vah_bn_tail_stats', 'vah_bn_tail_apply', 'vah_bn_tail_bwd_stats', 'vah_bn_tail_bwd_apply',
     'vah_bn_finalize_stats', 'vah_transpose_tokens', 'vah_maxpool3s2_fwd_bf16', 'vah_maxpool3s2_bwd_bf16',
     'vah_image_to_nhwc16_bf16', 'vah_bn_nhwc_ws_floats', 'vah_bn_nhwc_stats', 'vah_bn_nhwc_apply', 'vah_bn_nhwc_bwd_stats',

@@ -65,6 +65,8 @@ struct State {
     std::map<Key, std::shared_ptr<Problem>> problems;
     int mode = 1;            // 0: first heuristic answer, 1: time the heuristic candidates, 2: time all
     int candidates = 32;
+    void *probe = nullptr;   // device scratch of the candidate check (reference corner + two maxima)
+    int rejected = 0;        // candidates dropped by the check since the library was loaded
 };
 
 State &state() {
@@ -108,6 +110,7 @@ struct Call {
     const float *fin_part = nullptr;
     int fin_nparts = 0, fin_C = 0;
     float *fin_out = nullptr;
+    bool check = false;      // tuning: a reference corner has been recorded, compare every candidate with it
 };
 
 // split > 1: a strided batch over `split` equal slices of the K rows; the fp32 partial products
@@ -211,6 +214,53 @@ __global__ __launch_bounds__(256) void reduce_splits(const float *__restrict__ p
     }
 }
 
+// ---- numerical check of a tuning candidate: the 64 x 64 corner of its output against the corner the heuristic's FIRST
+// answer left (round 2 found exhaustive-mode algorithms that run without an error status and return wrong numbers).
+constexpr int kCorner = 64;
+template <typename OT>
+__global__ __launch_bounds__(256) void corner_probe(const OT *__restrict__ D, int64_t ldd, int M, int N, float *__restrict__ ref,
+                                                    unsigned *__restrict__ out2, int compare) {
+    float md = 0.f, mr = 0.f;
+    bool bad = false;
+    for (int i = threadIdx.x; i < kCorner * kCorner; i += 256) {
+        const int r = i / kCorner, cidx = i % kCorner;
+        if (r >= M || cidx >= N) continue;
+        const float v = (float)D[(int64_t)r * ldd + cidx];
+        if (!compare) {
+            ref[i] = v;
+        } else {
+            const float d = fabsf(v - ref[i]);
+            bad = bad || !(d == d) || !(v == v);
+            md = fmaxf(md, d == d ? d : 0.f);
+            mr = fmaxf(mr, fabsf(ref[i]));
+        }
+    }
+    if (compare) {      // non-negative floats order like their bit patterns
+        atomicMax(out2, __float_as_uint(bad ? INFINITY : md));
+        atomicMax(out2 + 1, __float_as_uint(mr));
+    }
+}
+
+// -> true if the output now in c.D agrees with the reference corner (or, with `record`, stores it as the reference)
+bool corner_check(State &S, const Call &c, bool record) {
+    if (!S.probe && hipMalloc(&S.probe, (kCorner * kCorner + 2) * sizeof(float)) != hipSuccess) return true;      // cannot check: accept
+    float *ref = (float *)S.probe;
+    unsigned *out2 = (unsigned *)(ref + kCorner * kCorner);
+    if (!record && hipMemsetAsync(out2, 0, 8, c.st) != hipSuccess) return true;
+    if (c.k.d32)
+        hipLaunchKernelGGL(corner_probe<float>, dim3(1), dim3(256), 0, c.st, (const float *)c.D, c.k.ldd, (int)c.k.M, (int)c.k.N, ref,
+                           out2, record ? 0 : 1);
+    else
+        hipLaunchKernelGGL(corner_probe<__bf16>, dim3(1), dim3(256), 0, c.st, (const __bf16 *)c.D, c.k.ldd, (int)c.k.M, (int)c.k.N,
+                           ref, out2, record ? 0 : 1);
+    if (record) return true;
+    float h[2] = {0.f, 0.f};
+    if (hipMemcpyAsync(h, out2, 8, hipMemcpyDeviceToHost, c.st) != hipSuccess || hipStreamSynchronize(c.st) != hipSuccess) return true;
+    // same operands, fp32 accumulation in a different order, bf16 or fp32 result: 2^-6 of the corner's largest value is
+    // far above any legitimate difference and far below a wrong tile
+    return h[0] <= 0.015625f * fmaxf(h[1], 1e-20f);
+}
+
 hipblasStatus_t run(State &S, const Call &c, Problem &p, const hipblasLtMatmulAlgo_t &algo, size_t ws_need, int split) {
     const size_t pb = partial_bytes(c.k, split);
     if (pb + ws_need > c.ws_bytes) return HIPBLAS_STATUS_ALLOC_FAILED;
@@ -301,11 +351,18 @@ hipblasStatus_t choose_for_split(State &S, const Call &c, Problem &p, int split,
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return HIPBLAS_STATUS_ALLOC_FAILED;
     float best = -1.f;
     size_t best_i = 0;
+    // the yardstick of the candidate check: what the heuristic's first answer for the UNSPLIT problem computes
+    // (recorded once per problem by choose(); here only compared)
     // coarse pass over everything, then a longer look at the best few
     std::vector<std::pair<float, size_t>> timed;
     for (size_t i = 0; i < cand.size(); ++i) {
         const float us = time_algo(S, c, p, cand[i].algo, cand[i].workspaceSize, split, e0, e1, 3);
-        if (us > 0.f) timed.emplace_back(us, i);
+        if (us <= 0.f) continue;
+        if (c.check && !corner_check(S, c, false)) {        // ran, but not to the same numbers: never a candidate
+            ++S.rejected;
+            continue;
+        }
+        timed.emplace_back(us, i);
     }
     std::sort(timed.begin(), timed.end());
     for (size_t j = 0; j < std::min<size_t>(timed.size(), 4); ++j) {
@@ -347,6 +404,24 @@ hipblasStatus_t choose(State &S, const Call &call, Choice &out) {
     Call c = call;                       // candidates are timed without the piggy-backed finalize job
     c.fin_part = nullptr;
     const std::vector<int> splits = split_candidates(S, c);
+    if (S.mode != 0) {
+        // reference for the candidate check: the heuristic's first answer on the unsplit problem
+        Problem p0;
+        if (make_problem(c, p0, 1) == HIPBLAS_STATUS_SUCCESS) {
+            hipblasLtMatmulPreference_t pref = nullptr;
+            if (hipblasLtMatmulPreferenceCreate(&pref) == HIPBLAS_STATUS_SUCCESS) {
+                const uint64_t wsmax = c.ws_bytes;
+                hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsmax, sizeof(wsmax));
+                hipblasLtMatmulHeuristicResult_t first;
+                int got = 0;
+                if (hipblasLtMatmulAlgoGetHeuristic(S.handle, p0.desc, p0.la, p0.lb, p0.ld, p0.ld, pref, 1, &first, &got) ==
+                        HIPBLAS_STATUS_SUCCESS && got == 1 &&
+                    run(S, c, p0, first.algo, first.workspaceSize, 1) == HIPBLAS_STATUS_SUCCESS)
+                    c.check = corner_check(S, c, true);
+                hipblasLtMatmulPreferenceDestroy(pref);
+            }
+        }
+    }
     hipblasStatus_t last = HIPBLAS_STATUS_NOT_SUPPORTED;
     bool have = false;
     for (int split : splits) {
@@ -453,7 +528,10 @@ static int gemm_impl(const char *fn, int trans_a, int trans_b, int64_t M, int64_
     c.fin_C = (int)fin_C;
     c.fin_out = fin_out;
     hipblasStatus_t s = HIPBLAS_STATUS_SUCCESS;
-    LaunchScope scope("gemm_bf16", (M * K + K * N) * 2 + M * N * (d_is_f32 ? 4 : 2), c.st);
+    // named by the product's role in a Linear layer: nt = forward (x W^T), nn = input gradient (g W), tn = weight gradient
+    // (g^T x); flops for the MFMA roofline rows of bench.py
+    const char *role = trans_a ? (fin_part ? "gemm_tn_fin" : "gemm_tn") : (trans_b ? "gemm_nt" : "gemm_nn");
+    LaunchScope scope(role, (M * K + K * N) * 2 + M * N * (d_is_f32 ? 4 : 2), c.st, 0, 2 * M * N * K);
     auto it = S.table.find(c.k);
     if (it != S.table.end() && !it->second.resolved) {
         Problem p;
@@ -492,6 +570,12 @@ static int gemm_impl(const char *fn, int trans_a, int trans_b, int64_t M, int64_
 
 // Version of the hipBLASLt build behind the dispatcher (algorithm indices of a dumped table are only
 // meaningful for the same build); < 0 on error.
+int64_t vah_gemm_rejected_candidates(void) {
+    vah::State &S = vah::state();
+    std::lock_guard<std::mutex> lock(S.mu);
+    return S.rejected;
+}
+
 int64_t vah_gemm_library_version(void) {
     using namespace vah;
     clear_error();

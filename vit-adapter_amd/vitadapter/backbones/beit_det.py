@@ -172,7 +172,7 @@ class BEiT(nn.Module):
     def init_weights(self, pretrained=None):
         if isinstance(pretrained, str):
             from ..checkpoint import load_checkpoint
-            load_checkpoint(self, pretrained, strict=False)
+            load_checkpoint(self, pretrained, strict=False, flavour='det')
 
     def _init_weights(self, m):
         if isinstance(m, nn.Linear):

@@ -75,8 +75,31 @@ def resize_rel_pos_bias_table(table, dst_num_pos, dst_patch_shape):
     return torch.cat((torch.cat(heads, dim=-1), extra), dim=0)
 
 
-def adapt_state_dict(model, state_dict, logger=None):
-    """The key surgery and interpolation of checkpoint.py:341-505 on a plain dict; returns the new dict."""
+def resize_rel_pos_bias_table_det(table, dst_num_pos):
+    """Detection flavour (/root/reference/detection/mmcv_custom/checkpoint.py:379-445): the model's tables have NO rows for
+    the class token (per-block (2 w - 1)^2 tables of windowed / global blocks), the checkpoint's have 3: they are always
+    dropped - also when the sizes agree - and the body is resized on the geometric grid from sqrt(src - 3) to
+    sqrt(dst) per side.  No second bicubic pass (commented out in the reference, :476-491)."""
+    from scipy.interpolate import RectBivariateSpline
+    src_num_pos, num_heads = table.shape
+    num_extra = 3
+    src_size = int((src_num_pos - num_extra) ** 0.5)
+    dst_size = int(dst_num_pos ** 0.5)
+    body = table[:-num_extra, :]
+    if src_size == dst_size:
+        return body
+    x, dx = _geometric_coordinates(src_size, dst_size)
+    heads = []
+    for i in range(num_heads):
+        z = body[:, i].view(src_size, src_size).float().numpy().astype(np.float64)
+        spline = RectBivariateSpline(x, x, z, kx=3, ky=3, s=0)
+        heads.append(torch.tensor(spline(dx, dx), dtype=torch.float32).contiguous().view(-1, 1).to(table.device))
+    return torch.cat(heads, dim=-1)
+
+
+def adapt_state_dict(model, state_dict, logger=None, flavour='seg'):
+    """The key surgery and interpolation of checkpoint.py:341-505 on a plain dict; returns the new dict.
+    flavour 'det': the relative-position tables as the detection loader treats them (resize_rel_pos_bias_table_det)."""
     state_dict = dict(state_dict)
     keys = list(state_dict.keys())
     if keys and keys[0].startswith('module.'):
@@ -101,7 +124,12 @@ def adapt_state_dict(model, state_dict, logger=None):
         if 'relative_position_index' in key:
             state_dict.pop(key)
         if 'relative_position_bias_table' in key and key in own:
-            state_dict[key] = resize_rel_pos_bias_table(state_dict[key], own[key].size(0), model.patch_embed.patch_shape)
+            if flavour == 'det':
+                if model.patch_embed.patch_shape[0] != model.patch_embed.patch_shape[1]:
+                    raise NotImplementedError()
+                state_dict[key] = resize_rel_pos_bias_table_det(state_dict[key], own[key].size(0))
+            else:
+                state_dict[key] = resize_rel_pos_bias_table(state_dict[key], own[key].size(0), model.patch_embed.patch_shape)
     if 'pos_embed' in state_dict and getattr(model, 'pos_embed', None) is not None:
         pe = state_dict['pos_embed']
         emb = pe.shape[-1]
@@ -115,7 +143,7 @@ def adapt_state_dict(model, state_dict, logger=None):
             tokens = F.interpolate(tokens, size=(new, new), mode='bicubic', align_corners=False)
             state_dict['pos_embed'] = torch.cat((extra, tokens.permute(0, 2, 3, 1).flatten(1, 2)), dim=1)
     for key in [k for k in state_dict if 'relative_position_bias_table' in k]:
-        if key not in own:
+        if key not in own or flavour == 'det':
             continue
         pre, cur = state_dict[key], own[key]
         L1, nH1 = pre.size()
@@ -130,7 +158,7 @@ def adapt_state_dict(model, state_dict, logger=None):
     return state_dict
 
 
-def load_checkpoint(model, filename, map_location='cpu', strict=False, logger=None):
+def load_checkpoint(model, filename, map_location='cpu', strict=False, logger=None, flavour='seg'):
     ckpt = _read(filename, map_location)
     if not isinstance(ckpt, dict):
         raise RuntimeError('No state_dict found in checkpoint file %s' % filename)
@@ -139,21 +167,32 @@ def load_checkpoint(model, filename, map_location='cpu', strict=False, logger=No
         if key in ckpt and isinstance(ckpt[key], dict):
             state = ckpt[key]
             break
-    # a detector / segmentor checkpoint carries the backbone under `backbone.` (not in the reference's loader, which
-    # is only ever given backbone files; harmless for those)
-    if state and all(k.startswith('backbone.') for k in state):
-        state = {k[len('backbone.'):]: v for k, v in state.items()}
-    state = adapt_state_dict(model, state, logger)
+    # a detector / segmentor checkpoint carries the backbone under `backbone.` beside neck / head keys (not in the
+    # reference's loader, which is only ever given backbone files; harmless for those): keep the backbone's keys
+    if state and any(k.startswith('backbone.') for k in state):
+        state = {k[len('backbone.'):]: v for k, v in state.items() if k.startswith('backbone.')}
+    state = adapt_state_dict(model, state, logger, flavour)
+    # the reference's load_state_dict (checkpoint.py:43-107) records a size mismatch and goes on; torch raises: report
+    # such keys with the missing ones instead
+    own = model.state_dict()
+    mismatched = [k for k, v in state.items() if k in own and tuple(own[k].shape) != tuple(v.shape)]
+    for k in mismatched:
+        state.pop(k)
     missing, unexpected = model.load_state_dict(state, strict=False)
     missing = [k for k in missing if 'num_batches_tracked' not in k]
-    if missing or unexpected:
+    if missing or unexpected or mismatched:
         msg = 'The model and loaded state dict do not match exactly\n'
         if unexpected:
             msg += 'unexpected key in source state_dict: %s\n' % ', '.join(unexpected)
         if missing:
             msg += 'missing keys in source state_dict: %s\n' % ', '.join(missing)
+        if mismatched:
+            msg += 'size mismatch (not loaded): %s\n' % ', '.join(mismatched)
         if strict:
             raise RuntimeError(msg)
         if logger is not None:
             logger.warning(msg)
+        else:                       # the reference prints when it has no logger (checkpoint.py:97-108)
+            import warnings
+            warnings.warn(msg)
     return ckpt

@@ -352,33 +352,61 @@ class _SideStream:
     def __init__(self):
         self.streams = {}
         self.pending = {}          # device index -> (main stream, [tensors kept alive])
-        self.uses = {}             # id(parameter) -> [uses in the open forward epoch]
+        self.deferred = {}         # id(parameter) -> gradients that reached the parameter since its gradient was deferred (this pass)
+        self.hooked = {}           # id(parameter) -> weakref (the parameters that carry the ordering hook)
 
     def begin_epoch(self):
-        self.uses = {}
         for idx in list(self.pending):      # a backward pass that died before its callback: join now, never leave a fork open
             self.join(idx)
+        self.deferred.clear()
 
-    def note(self, param):
-        """Called by a forward that uses ``param`` once; returns the token its backward hands to ``may_defer``.
-        A gradient may only be left on the side stream if autograd will merely STORE it: the parameter has no .grad
-        yet (no gradient accumulation across micro-batches) and is used once in the forward (a second use - shared
-        weights, an activation-checkpoint recompute - makes autograd ADD the two gradients on the main stream)."""
-        if not param.is_leaf or param.grad is not None or not (BF16_COPIES.epoch & 1):
+    def note(self, weight, bias):
+        """Forward: weak references to the parameters whose gradients the backward may leave on the side stream.  The
+        DECISION is taken at backward time (may_defer): a decision taken in the forward does not survive two forwards
+        before one backward, a second backward with retain_graph, or a second use of the weight by another operator."""
+        import weakref
+        if not weight.is_leaf or (bias is not None and not bias.is_leaf) or not (BF16_COPIES.epoch & 1):
             return None
-        token = self.uses.get(id(param))
-        if token is None:
-            token = self.uses[id(param)] = [0]
-        token[0] += 1
-        return token
+        return (weakref.ref(weight), weakref.ref(bias) if bias is not None else None)
+
+    def _order_hook(self, pid):
+        def hook(grad):
+            n = self.deferred.get(pid)
+            if n is not None:
+                self.deferred[pid] = n + 1
+                # n == 0: the deferred gradient itself arrives - autograd only stores it.  Any further gradient for this
+                # parameter in the same pass (a second forward of the module, another operator using the weight) is ADDED
+                # to the stored one on the current stream: that add has to come behind the side stream's writes
+                if n >= 1 and grad.is_cuda:
+                    idx = grad.device.index if grad.device.index is not None else torch.cuda.current_device()
+                    side = self.streams.get(idx)
+                    if side is not None:
+                        torch.cuda.current_stream(grad.device).wait_stream(side)
+            return None
+        return hook
 
     def may_defer(self, token, dev):
-        if token is None or token[0] != 1 or not (ENABLED['wgrad_overlap'] and dev.type == 'cuda'):
+        """Backward: may this node's weight / bias gradients be produced on the side stream?  Only if autograd will
+        merely STORE them: every parameter alive, without a .grad (no accumulation across micro-batches or backward
+        passes) and without a gradient already deferred in this pass."""
+        if token is None or not (ENABLED['wgrad_overlap'] and dev.type == 'cuda'):
+            return False
+        params = [r() for r in token if r is not None]
+        if any(p is None or p.grad is not None or id(p) in self.deferred for p in params):
             return False
         if torch.cuda.is_current_stream_capturing():
             return False               # measured: ~80 fork / join edges per step cost a replayed HIP graph 0.35 ms more than the overlap gains
         import torch.distributed as dist
-        return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            return False
+        import weakref
+        for p in params:
+            self.deferred[id(p)] = 0
+            ref = self.hooked.get(id(p))
+            if ref is None or ref() is not p:               # once per parameter: orders later gradients behind the side stream
+                p.register_hook(self._order_hook(id(p)))
+                self.hooked[id(p)] = weakref.ref(p)
+        return True
 
     def fork(self, dev, keep):
         """-> the side stream, ordered behind everything enqueued on the current stream so far."""
@@ -400,6 +428,8 @@ class _SideStream:
         if entry is not None:
             entry[0].wait_stream(self.streams[idx])
             entry[1].clear()
+        if not self.pending:
+            self.deferred.clear()
 
 
 SIDE = _SideStream()
@@ -421,7 +451,7 @@ class _LinearBF16(torch.autograd.Function):
         y = gemm_bf16(x2, wb, trans_b=True, bias=bias.detach() if bias is not None else None)
         ctx.save_for_backward(x2, wb)
         ctx.has_bias = bias is not None
-        ctx.side = SIDE.note(weight) if (bias is None or (bias.is_leaf and bias.grad is None)) else None
+        ctx.side = SIDE.note(weight, bias)
         ctx.in_shape = x.shape
         ctx.in_dtype = x.dtype
         return y.view(*x.shape[:-1], weight.shape[0])
