@@ -77,6 +77,9 @@ def parse():
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' lets several ranks share one GPU for a functional rehearsal of the "
                          "N>1 path on a 1-GPU box (not a performance mode)")
+    ap.add_argument('--family-steps', type=int, default=5,
+                    help='untimed eager steps after the timed region that put every library entry point on the `kernels` list '
+                         '(GEMMs by role with MFMA fractions, LayerNorm / residual / column-sum / conv / BatchNorm-tail rows); 0: off')
     ap.add_argument('--profile-kernels', default='msda_,attn_',
                     help='HIP-event timing inside the timed region for the library entry points whose name '
                          'starts with one of these comma-separated prefixes ("" = all of them, costs ~2 %%; '
@@ -129,6 +132,8 @@ def setup_gemm_tuning(args):
         if os.path.exists(TUNING_FILE):
             tunable.read_file(TUNING_FILE)
 
+
+FAMILY_PREFIXES = 'gemm_,colsum_,layernorm,residual_,scale_residual,dwconv_,bn_,conv_,gelu_,maxpool,transpose,pixel_shuffle,patchify,relpos,spm_'
 
 MSDA_SOURCES = ('msda.hip', 'msda_fused.hip', 'msda_tile.hip', 'msda_fwd_win.hip', 'msda_common.h')
 
@@ -473,6 +478,17 @@ def main():
         _vah.prof_enable(False)
     prof = _vah.prof_report()
     assert torch.isfinite(loss).item(), 'loss is not finite'
+    # the rest of the step by operator family (55 % of the step had no row): a few more eager steps, untimed,
+    # with HIP events on every library entry point of the families below (event pairs on ~900 launches per step cost
+    # host time, so never inside the timed region)
+    fam_prof = {}
+    if args.family_steps > 0 and world == 1:
+        _vah.prof_enable(True, FAMILY_PREFIXES)
+        for _ in range(args.family_steps):
+            step()
+        fence()
+        _vah.prof_enable(False)
+        fam_prof = _vah.prof_report()
 
     dt = dp.max_over_ranks(dt, dev)
 
@@ -492,6 +508,16 @@ def main():
                         'bytes_are': 'moved for the IO dtypes of the launch: value, out / grad_out, offsets, logits and their '
                                      'gradients in %s (grad_value too: the tile pass stores it in the value dtype)' % args.dtype,
                         'frac_fp32_definition': msda[dom].get('frac_fp32_definition')}
+        for name, r in fam_prof.items():
+            if r['calls'] and name not in kernels:
+                kernels[name] = kernel_row(r, args.family_steps)
+        gemm = [r for n_, r in fam_prof.items() if n_.startswith('gemm_') and r['calls']]
+        if gemm:        # the Linear layers as one family: all matrix-core flops over all their launch time (split-K reductions included)
+            fl, ms = sum(r['flops'] for r in gemm), sum(r['total_ms'] for r in gemm)
+            kernels['gemm_family'] = {'calls_per_step': sum(r['calls'] for r in gemm) / args.family_steps,
+                                      'ms_per_step': round(ms / args.family_steps, 3), 'bound': 'mfma',
+                                      'achieved_TFLOPs': round(fl / (ms * 1e-3) / 1e12, 1),
+                                      'frac_of_mfma_peak': round(fl / (ms * 1e-3) / MFMA_PEAK, 4)}
         if args.boundary_iters > 0 and world == 1:
             kernels.update(boundary_kernels(dev, args.boundary_iters))
         line = {
@@ -514,7 +540,9 @@ def main():
                        'kernel_rows': ('HIP events over %d eager steps right after the timed region (events cannot be read '
                                        'back from inside a graph)' % args.steps) if use_graph else 'HIP events inside the timed region',
                        'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
-                       'backend': args.backend if world > 1 else None},
+                       'backend': args.backend if world > 1 else None,
+                       # hipBLASLt algorithms the dispatcher's whole-output check refused (csrc/gemm.hip)
+                       'gemm_candidates_rejected': int(_vah.lib.vah_gemm_rejected_candidates())},
             'roofline': roofline,
             'kernels': kernels,
         }

@@ -107,8 +107,13 @@ int vah_msda_backward_f64(const double *value, const int64_t *shapes, const int6
  * the fallback of vah_msda_fused_backward_tiled below, which is what the modules call.
  * ------------------------------------------------------------------------------------ */
 int vah_msda_fused_supported(int64_t D, int64_t L, int64_t P);
+/* offsets_stride / logits_stride: elements between the offsets / logits of consecutive (n, q, m) rows; 0 = contiguous
+ * tensors (L*P*2 and L*P).  The module keeps both in ONE fp32 matrix - the output of the paired Linear with its rows
+ * ordered [head][offsets | logits] - so that a row's 3*L*P numbers share cache lines: strides 3*L*P, logits pointer =
+ * offsets pointer + 2*L*P (ops/modules/ms_deform_attn.py). */
 int vah_msda_fused_forward(const void *value, int value_dtype, const int64_t *shapes, const int64_t *lsi,
                            const void *offsets, const void *logits, int param_dtype,
+                           int64_t offsets_stride, int64_t logits_stride,
                            const float *ref, int64_t ref_levels,
                            int64_t N, int64_t S, int64_t M, int64_t D, int64_t L, int64_t Lq, int64_t P,
                            void *out, void *stream);
@@ -121,22 +126,21 @@ int vah_msda_fused_backward(const void *value, int value_dtype, const int64_t *s
 /* ------------------------------------------------------------------------------------
  * Fused forward over LDS value windows (csrc/msda_fwd_win.hip), single-level calls (L == 1, D == 32, P == 4,
  * reference points shared by the batch: the adapter's extractor).  Same result as vah_msda_fused_forward for ANY
- * offsets; the schedule only decides which corner rows are served from LDS:
- *   perm       (Lq,)           int32  the queries group by group (a permutation of [0, Lq))
- *   group_off  (ngroups + 1,)  int32  group g owns perm[group_off[g] .. group_off[g+1])
- *   group_win  (ngroups, 4)    int32  {y0, x0, h, w}: the window of the value map (inside the map) staged for
- *                                     the group; corners outside it are read from global memory
- *   max_win_px                        largest h * w (sizes the LDS: max_win_px * 32 * sizeof(value) <= 64 KB)
- *   H, W, level_start                 the level's geometry (host values)
- * A workgroup is (n, group, head): it stages the window once, then one lane per query evaluates its four
+ * offsets; the windows only decide which corner rows are served from LDS.  The queries are grouped by the 8 x 8-pixel
+ * tile of the value map their reference point falls in; a group's window is the tile + halo + 1 pixels on every side.
+ * The schedule (permutation of the queries, group ranges) is built ON THE DEVICE by a first small kernel from `ref`
+ * and the device copies of spatial_shapes / level_start_index: no host copy of the geometry, nothing cached by tensor
+ * identity, capturable in a HIP graph with fresh shape tensors.
+ *   ws / ws_bytes : device workspace of at least vah_msda_win_ws_bytes(S, Lq) bytes, 16-byte aligned
+ * A workgroup walks (n, group, head) items: it stages the window once, then one lane per query evaluates its four
  * samples against it (replaces ms_deform_im2col_cuda.cuh:237-299 + the module's softmax / location lines).
  * ------------------------------------------------------------------------------------ */
-int vah_msda_fused_forward_win(const void *value, int value_dtype, const void *offsets, const void *logits,
-                               int param_dtype, const float *ref, const int32_t *perm,
-                               const int32_t *group_off, const int32_t *group_win, int64_t ngroups,
-                               int64_t max_win_px, int64_t H, int64_t W, int64_t level_start, int64_t N,
-                               int64_t S, int64_t M, int64_t D, int64_t Lq, int64_t P, void *out,
-                               void *stream);
+int64_t vah_msda_win_ws_bytes(int64_t S, int64_t Lq);      /* < 0: not supported (Lq > 2^18) */
+int vah_msda_fused_forward_win(const void *value, int value_dtype, const int64_t *shapes, const int64_t *lsi,
+                               const void *offsets, const void *logits, int param_dtype,
+                               int64_t offsets_stride, int64_t logits_stride, const float *ref,
+                               int64_t N, int64_t S, int64_t M, int64_t D, int64_t Lq, int64_t P,
+                               int64_t halo, void *ws, int64_t ws_bytes, void *out, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * TILED BACKWARD: grad_value without atomics and without a zero-fill, for ANY sampling locations
@@ -161,7 +165,9 @@ int vah_msda_fused_forward_win(const void *value, int value_dtype, const void *o
  *   needs D == 32, P == 4, 1 <= L <= 4 (VAH_E_UNSUPPORTED otherwise: use the functions above)
  * vah_msda_fused_backward_tiled: grad_value_dtype 0 = fp32, 1 = bf16 (bf16 values only); grad_param_dtype: type of
  * d_offsets / d_logits, = param_dtype or bf16 for fp32 offsets / logits (bf16 values only: the module keeps the
- * sampling offsets in fp32 under autocast and hands bf16 gradients to its Linear layers).
+ * sampling offsets in fp32 under autocast and hands bf16 gradients to its Linear layers).  The strides are those of
+ * vah_msda_fused_forward, for the inputs and for the gradients (0 = contiguous); with strides the gradient kernels of
+ * fp32 values (msda_fused.hip) are not available: VAH_E_UNSUPPORTED.
  * ------------------------------------------------------------------------------------ */
 int64_t vah_msda_tile_ws_bytes(int64_t N, int64_t S, int64_t M, int64_t L, int64_t Lq, int64_t P);     /* < 0: not supported */
 int vah_msda_backward_tiled_f32(const float *value, const int64_t *shapes, const int64_t *lsi,
@@ -171,11 +177,13 @@ int vah_msda_backward_tiled_f32(const float *value, const int64_t *shapes, const
                                 int64_t ws_bytes, void *stream);
 int vah_msda_fused_backward_tiled(const void *value, int value_dtype, const int64_t *shapes,
                                   const int64_t *lsi, const void *offsets, const void *logits,
-                                  int param_dtype, const float *ref, int64_t ref_levels,
+                                  int param_dtype, int64_t offsets_stride, int64_t logits_stride,
+                                  const float *ref, int64_t ref_levels,
                                   const void *grad_out, int64_t N, int64_t S, int64_t M, int64_t D,
                                   int64_t L, int64_t Lq, int64_t P, void *grad_value,
                                   int grad_value_dtype, void *d_offsets, void *d_logits,
-                                  int grad_param_dtype, void *ws, int64_t ws_bytes, void *stream);
+                                  int grad_param_dtype, int64_t d_offsets_stride, int64_t d_logits_stride,
+                                  void *ws, int64_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Softmax attention of the ViT blocks, bf16, head_dim 64  

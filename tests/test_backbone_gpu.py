@@ -203,6 +203,9 @@ def test_fused_core_bf16_autocast_matches_unfused(monkeypatch, L, shapes, qshape
     """Under bf16 autocast the fused core reads the bf16 Linear outputs directly; the unfused
     sequence casts them to fp32 first.  Same information, so results agree to bf16 rounding."""
     from ops.modules import MSDeformAttn
+    from vitadapter import fused as vfused
+    # the one-node pair + core keeps the offsets in fp32 (its own test below): here both sides read the bf16 outputs
+    monkeypatch.setitem(vfused.ENABLED, 'pair_core', False)
     torch.manual_seed(4)
     m = MSDeformAttn(d_model=192, n_levels=L, n_heads=6, n_points=4, ratio=1.0).cuda()
     with torch.no_grad():
@@ -228,6 +231,75 @@ def test_fused_core_bf16_autocast_matches_unfused(monkeypatch, L, shapes, qshape
     for a, b, nm in zip(res[0], res[1], ('out', 'dquery', 'dfeat', 'd offsets.w', 'd attn.b', 'd value.w')):
         err = (a - b).abs().max().item()
         assert err <= 4e-2 * max(1.0, b.abs().max().item()), (nm, err)
+
+
+@pytest.mark.parametrize('L,shapes,qshapes', [(3, [(16, 16), (8, 8), (4, 4)], [(8, 8)]),
+                                              (1, [(8, 8)], [(16, 16), (8, 8), (4, 4)]),
+                                              (1, [(16, 24)], [(32, 48), (16, 24), (8, 12)]),
+                                              (4, [(8, 8), (4, 4), (2, 2), (1, 1)], [(8, 8), (4, 4), (2, 2), (1, 1)])])
+def test_pair_core_matches_fp32_offsets_module(L, shapes, qshapes):
+    """vitadapter/fused.py::_MSDAPairCore (offsets / logits GEMM with fp32 output read in place by the MSDA kernels,
+    bf16 gradients written into the pair GEMM's gradient matrix) against the module's arithmetic
+    (ops/modules/ms_deform_attn.py:108-128 of the reference) with that Linear pair evaluated in fp32 on the SAME
+    bf16-rounded operands, the fp32 core (MSDeformAttnFunction) and autograd.  Same sampling locations on both sides up
+    to fp32 accumulation order, so no sample changes its pixel cell; what differs is bf16 rounding of out, grad_value and
+    the offsets / logits gradients: 2e-2 of each tensor's maximum."""
+    from ops.functions import MSDeformAttnFunction
+    from ops.modules import MSDeformAttn
+    from vitadapter import fused as vfused
+    assert vfused.ENABLED['pair_core']
+    torch.manual_seed(4)
+    M, P, C = 6, 4, 192
+    m = MSDeformAttn(d_model=C, n_levels=L, n_heads=M, n_points=P, ratio=1.0).cuda()
+    with torch.no_grad():
+        m.sampling_offsets.weight.normal_(0, 0.02)
+        m.attention_weights.weight.normal_(0, 0.05)
+        m.attention_weights.bias.normal_(0, 0.3)
+    S, Lq = sum(h * w for h, w in shapes), sum(h * w for h, w in qshapes)
+    ref = cases.reference_grid(qshapes).cuda()
+    if L > 1:
+        ref = ref.expand(1, Lq, L, 2).contiguous()
+    hw = torch.as_tensor(shapes, dtype=torch.long).cuda()
+    lsi = cases.level_start_index(shapes).cuda()
+    N = 2
+    query = torch.randn(N, Lq, C, device='cuda')
+    feat = torch.randn(N, S, C, device='cuda')
+    gout = torch.randn(N, Lq, C, device='cuda')
+    names = ('out', 'dquery', 'dfeat', 'd offsets.w', 'd offsets.b', 'd attn.w', 'd attn.b', 'd value.w')
+
+    def grads(out, qq, ff):
+        out.float().backward(gout)
+        return (out.float().detach(), qq.grad, ff.grad, m.sampling_offsets.weight.grad.clone(),
+                m.sampling_offsets.bias.grad.clone(), m.attention_weights.weight.grad.clone(),
+                m.attention_weights.bias.grad.clone(), m.value_proj.weight.grad.clone())
+
+    qq, ff = query.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    m.zero_grad()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        assert vfused.msda_pair_core_ok(m, qq, m.value_proj(ff).view(N, S, M, C // M), ref)
+        out = m(qq, ref, ff, hw, lsi, None)
+    got = grads(out, qq, ff)
+
+    def rounded(t):                     # bf16 value, fp32 gradient straight through
+        return t + (t.to(torch.bfloat16).float() - t).detach()
+
+    qq, ff = query.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+    m.zero_grad()
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        value = m.value_proj(ff)
+    qr = rounded(qq).view(-1, C)
+    offsets = (qr @ rounded(m.sampling_offsets.weight).t() + m.sampling_offsets.bias).view(N, Lq, M, L, P, 2)
+    logits = (qr @ rounded(m.attention_weights.weight).t() + m.attention_weights.bias).view(N, Lq, M, L * P)
+    weights = torch.softmax(logits, -1).view(N, Lq, M, L, P)
+    wh = hw.flip(-1).float()
+    loc = ref[:, :, None, :, None, :] + offsets / wh[None, None, None, :, None, :]
+    core = MSDeformAttnFunction.apply(value.float().view(N, S, M, C // M), hw, lsi, loc, weights, 64)
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        out = m.output_proj(core.to(torch.bfloat16))
+    want = grads(out, qq, ff)
+    for a, b, nm in zip(got, want, names):
+        err = (a - b).abs().max().item()
+        assert err <= 2e-2 * max(1e-3, b.abs().max().item()), (nm, err, b.abs().max().item())
 
 
 @pytest.mark.parametrize('L,shapes,qshapes,scale', [

@@ -142,3 +142,44 @@ def test_tile_pass_overflowing_list_walks_all_queries():
                 (N, M, D, P, Lq, L, S, shapes))
     _check('out (overflow case)', out, w[0], True)
     _check('grad_value (overflow case)', gvb, w[1], True)
+
+
+@pytest.mark.parametrize('L,shapes,qshapes', [(1, [(16, 24)], [(32, 48), (16, 24), (8, 12)]), (3, [(32, 32), (16, 16), (8, 8)], [(16, 16)])])
+def test_fused_core_is_capturable_with_fresh_geometry_tensors(L, shapes, qshapes):
+    """forward (LDS-window schedule built on the device) and backward (tile pass planned on the
+    device) read the level geometry from the DEVICE tensors and nothing else - no D2H copy, no cache keyed on tensor
+    identity - so a HIP graph can capture them with geometry tensors that did not exist before the capture (the
+    reference's deform_inputs makes new ones every forward, adapter_modules.py:28-47), and the replay equals eager."""
+    from ops.functions import MSDeformAttnFusedFunction
+    torch.manual_seed(3)
+    N, M, D, P = 2, 6, 32, 4
+    S, Lq = sum(h * w for h, w in shapes), sum(h * w for h, w in qshapes)
+    value = torch.randn(N, S, M, D, device='cuda').bfloat16().requires_grad_(True)
+    off = (cases.ring_offsets(M, L, P).cuda()[None, None] + torch.randn(N, Lq, M, L, P, 2, device='cuda')).bfloat16().requires_grad_(True)
+    logit = torch.randn(N, Lq, M, L * P, device='cuda').bfloat16().requires_grad_(True)
+    ref0 = cases.reference_grid(qshapes).cuda()
+    hw0 = torch.as_tensor(shapes, dtype=torch.long, device='cuda')
+    lsi0 = cases.level_start_index(shapes).cuda()
+    gout = torch.randn(N, Lq, M * D, device='cuda').bfloat16()
+
+    def run():
+        hw, lsi, ref = hw0.clone(), lsi0.clone(), ref0.clone()          # fresh tensors: new data_ptr, new identity
+        out = MSDeformAttnFusedFunction.apply(value, hw, lsi, off, logit, ref)
+        return (out,) + torch.autograd.grad(out, [value, off, logit], gout)
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            want = [t.float().clone() for t in run()]
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        got = run()
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    for g, w, nm in zip(got, want, ('out', 'grad_value', 'd_offsets', 'd_logits')):
+        # list order inside a tile depends on atomics: sums may differ in the last bits between two runs
+        assert (g.float() - w).abs().max().item() <= 2e-2 * max(1.0, w.abs().max().item()), nm

@@ -77,35 +77,55 @@ def test_backward_uses_the_copy_of_its_own_forward_gpu():
 
 
 def test_side_stream_deferral_rules():
-    """Weight gradients may stay on the side stream only when autograd will merely store them.  The decision is taken at
-    BACKWARD time (vitadapter/fused.py::_SideStream.may_defer): parameter alive, leaf, without a .grad, no gradient of
-    this backward pass already deferred for it, no multi-rank process group."""
-    import torch
-    from vitadapter import fused
+    """A weight gradient may stay on the side stream (and be stored by the join instead of by autograd) only when this
+    backward pass does nothing with it but accumulate it into .grad (vitadapter/fused.py::_SideStream): leaf parameters
+    of an open forward epoch, no tensor hooks, AccumulateGrad scheduled - not under autograd.grad(), not when
+    backward(inputs=...) leaves the parameter out."""
     side = fused._SideStream()
-    w = torch.nn.Parameter(torch.zeros(4, 4))
+    w = torch.nn.Parameter(torch.zeros(4))
     b = torch.nn.Parameter(torch.zeros(4))
-    cpu = torch.device('cpu')
-    fused.BF16_COPIES.epoch = 1            # an open forward epoch
+    seen = {}
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, b):
+            ctx.tok = side.note(w, b)
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            seen['tok'] = ctx.tok
+            seen['ok'] = ctx.tok is not None and all(side._only_accumulated(r()) for r in ctx.tok)
+            return g, torch.zeros_like(w), torch.zeros_like(b)
+
+    x = torch.zeros(4, requires_grad=True)
+    assert side.may_defer(None, torch.device('cpu')) is False
+    Probe.apply(x, w, b).sum().backward()
+    assert seen['tok'] is None                                        # no forward epoch open: working copies are per use
+    fused.BF16_COPIES.epoch = 1
     try:
-        side.begin_epoch()
-        tok = side.note(w, b)
-        assert tok is not None and tok[0]() is w and tok[1]() is b
-        assert side.note(w.view(16), None) is None                   # not a leaf
-        assert side.may_defer(None, cpu) is False
-        assert side.may_defer(tok, cpu) is False                     # not a GPU tensor
-        if torch.cuda.is_available():
-            dev = torch.device('cuda', 0)
-            assert side.may_defer(tok, dev) is True                  # first gradient of the pass: deferred, parameters marked
-            assert side.may_defer(side.note(w, b), dev) is False     # a second node of the same weight in this pass: not again
-            side.begin_epoch()
-            w.grad = torch.zeros_like(w)                             # gradient accumulation across micro-batches / passes
-            assert side.may_defer(side.note(w, b), dev) is False
-            w.grad = None
-            assert side.may_defer(side.note(w, b), dev) is True
+        assert side.note(w.view(4), None) is None                     # not a leaf
+        Probe.apply(x, w, b).sum().backward()
+        assert seen['ok'] is True and seen['tok'][0]() is w and seen['tok'][1]() is b
+        assert side.may_defer(seen['tok'], torch.device('cpu')) is False          # not a GPU tensor
+        torch.autograd.grad(Probe.apply(x, w, b).sum(), [w])          # gradients are returned, not accumulated
+        assert seen['ok'] is False
+        Probe.apply(x, w, b).sum().backward(inputs=[x])               # the parameters are left out of this pass
+        assert seen['ok'] is False
+        Probe.apply(x, w, b).sum().backward(inputs=[w, b])
+        assert seen['ok'] is True
+        h = w.register_hook(lambda g: g)                              # somebody looks at the gradient in mid-pass
+        Probe.apply(x, w, b).sum().backward()
+        assert seen['ok'] is False
+        h.remove()
+        Probe.apply(x, w, b).sum().backward()
+        assert seen['ok'] is True
+        h = b.register_post_accumulate_grad_hook(lambda p: None)      # e.g. an optimizer step inside the backward
+        Probe.apply(x, w, b).sum().backward()
+        assert seen['ok'] is False
+        h.remove()
     finally:
         fused.BF16_COPIES.epoch = 0
-        side.deferred.clear()
 
 
 def _lin_grads(lin, holder, xs, retain=False, extra_use=False):

@@ -14,7 +14,7 @@ import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'lib', 'libvitadapter_hip.so')
-ABI_VERSION = 35
+ABI_VERSION = 36
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -68,18 +68,20 @@ lib.vah_attn_win_bwd_bf16.restype = ctypes.c_int
 _ci = ctypes.c_int
 lib.vah_msda_fused_supported.argtypes = [_i64, _i64, _i64]
 lib.vah_msda_fused_supported.restype = ctypes.c_int
-lib.vah_msda_fused_forward.argtypes = [_p, _ci, _p, _p, _p, _p, _ci, _p, _i64] + [_i64] * 7 + [_p, _p]
+lib.vah_msda_fused_forward.argtypes = [_p, _ci, _p, _p, _p, _p, _ci, _i64, _i64, _p, _i64] + [_i64] * 7 + [_p, _p]
 lib.vah_msda_fused_forward.restype = ctypes.c_int
 lib.vah_msda_fused_backward.argtypes = [_p, _ci, _p, _p, _p, _p, _ci, _p, _i64, _p] + [_i64] * 7 + [_p] * 4
 lib.vah_msda_fused_backward.restype = ctypes.c_int
-lib.vah_msda_fused_forward_win.argtypes = [_p, _ci, _p, _p, _ci, _p, _p, _p, _p] + [_i64] * 11 + [_p, _p]
+lib.vah_msda_fused_forward_win.argtypes = [_p, _ci, _p, _p, _p, _p, _ci, _i64, _i64, _p] + [_i64] * 7 + [_p, _i64, _p, _p]
+lib.vah_msda_win_ws_bytes.argtypes = [_i64, _i64]
+lib.vah_msda_win_ws_bytes.restype = _i64
 lib.vah_msda_fused_forward_win.restype = ctypes.c_int
 lib.vah_msda_tile_ws_bytes.argtypes = [_i64] * 6
 lib.vah_msda_tile_ws_bytes.restype = _i64
 lib.vah_msda_backward_tiled_f32.argtypes = [_p] * 6 + [_i64] * 7 + [_p] * 3 + [_p, _i64, _p]
 lib.vah_msda_backward_tiled_f32.restype = ctypes.c_int
-lib.vah_msda_fused_backward_tiled.argtypes = ([_p, _ci, _p, _p, _p, _p, _ci, _p, _i64, _p] + [_i64] * 7
-                                              + [_p, _ci, _p, _p, _ci, _p, _i64, _p])
+lib.vah_msda_fused_backward_tiled.argtypes = ([_p, _ci, _p, _p, _p, _p, _ci, _i64, _i64, _p, _i64, _p] + [_i64] * 7
+                                              + [_p, _ci, _p, _p, _ci, _i64, _i64, _p, _i64, _p])
 lib.vah_msda_fused_backward_tiled.restype = ctypes.c_int
 _f = ctypes.c_float
 lib.vah_layernorm_fwd_f32_bf16.argtypes = [_p, _p, _p, _i64, _i64, _f, _p, _p, _p, _p]
@@ -158,7 +160,7 @@ EXPORTS = (
     'vah_msda_forward_f32', 'vah_msda_forward_f64',
     'vah_msda_backward_f32', 'vah_msda_backward_f64',
     'vah_msda_fused_supported', 'vah_msda_fused_forward', 'vah_msda_fused_backward',
-    'vah_msda_fused_forward_win', 'vah_msda_tile_ws_bytes', 'vah_msda_backward_tiled_f32', 'vah_msda_fused_backward_tiled',
+    'vah_msda_fused_forward_win', 'vah_msda_win_ws_bytes', 'vah_msda_tile_ws_bytes', 'vah_msda_backward_tiled_f32', 'vah_msda_fused_backward_tiled',
     'vah_pixel_shuffle2_bf16', 'vah_patchify_bf16', 'vah_attn_bias_fwd_bf16', 'vah_attn_bias_bwd_bf16', 'vah_relpos_bias_build', 'vah_relpos_bias_grad_ws_floats',
     'vah_relpos_bias_grad', 'vah_attn_padded_len', 'vah_attn_fwd_bf16', 'vah_attn_bwd_workspace_bytes', 'vah_attn_bwd_bf16',
     'vah_attn_win_fwd_bf16', 'vah_attn_win_bwd_bf16',
@@ -235,28 +237,6 @@ def prof_report():
         out[name] = dict(calls=int(calls), total_ms=float(ms), bytes=int(nbytes), def_bytes=int(dbytes),
                          flops=int(flops))
     return out
-
-
-_HOST_GEOM = {}
-
-
-def host_geometry(spatial_shapes, level_start_index):
-    """HOST copies of the (L, 2) int64 spatial_shapes / (L,) level_start_index device tensors, as the
-    tiled MSDA backward needs them to size its grid and workspace (include/vitadapter_hip.h, TILED
-    BACKWARD).  One device->host read the first time a tensor pair is seen, then cached; the cache keeps
-    the tensors alive so that a data_ptr cannot come back with other contents.  Returns
-    (shapes_ctypes, lsi_ctypes, shapes_list)."""
-    key = (spatial_shapes.data_ptr(), spatial_shapes._version, level_start_index.data_ptr(),
-           level_start_index._version, str(spatial_shapes.device), tuple(spatial_shapes.shape))
-    hit = _HOST_GEOM.get(key)
-    if hit is None:
-        sh = [int(v) for hw in spatial_shapes.tolist() for v in hw]
-        ls = [int(v) for v in level_start_index.tolist()]
-        hit = ((ctypes.c_int64 * len(sh))(*sh), (ctypes.c_int64 * len(ls))(*ls), sh, spatial_shapes, level_start_index)
-        if len(_HOST_GEOM) > 256:
-            _HOST_GEOM.clear()
-        _HOST_GEOM[key] = hit
-    return hit[0], hit[1], hit[2]
 
 
 GEMM_EPI_NONE, GEMM_EPI_BIAS = 0, 1

@@ -103,7 +103,7 @@ LaunchScope::~LaunchScope() {
 
 extern "C" {
 
-int vah_abi_version(void) { return 35; }
+int vah_abi_version(void) { return 36; }
 
 const char *vah_last_error(void) { return vah::g_err; }
 

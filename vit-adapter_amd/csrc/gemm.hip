@@ -65,7 +65,7 @@ struct State {
     std::map<Key, std::shared_ptr<Problem>> problems;
     int mode = 1;            // 0: first heuristic answer, 1: time the heuristic candidates, 2: time all
     int candidates = 32;
-    void *probe = nullptr;   // device scratch of the candidate check (reference corner + two maxima)
+    void *probe = nullptr;   // device scratch of the candidate check (two maxima)
     int rejected = 0;        // candidates dropped by the check since the library was loaded
 };
 
@@ -110,7 +110,7 @@ struct Call {
     const float *fin_part = nullptr;
     int fin_nparts = 0, fin_C = 0;
     float *fin_out = nullptr;
-    bool check = false;      // tuning: a reference corner has been recorded, compare every candidate with it
+    const float *ref = nullptr;      // tuning: the reference product (M x N fp32) every candidate is held to
 };
 
 // split > 1: a strided batch over `split` equal slices of the K rows; the fp32 partial products
@@ -214,51 +214,115 @@ __global__ __launch_bounds__(256) void reduce_splits(const float *__restrict__ p
     }
 }
 
-// ---- numerical check of a tuning candidate: the 64 x 64 corner of its output against the corner the heuristic's FIRST
-// answer left (round 2 found exhaustive-mode algorithms that run without an error status and return wrong numbers).
-constexpr int kCorner = 64;
-template <typename OT>
-__global__ __launch_bounds__(256) void corner_probe(const OT *__restrict__ D, int64_t ldd, int M, int N, float *__restrict__ ref,
-                                                    unsigned *__restrict__ out2, int compare) {
-    float md = 0.f, mr = 0.f;
-    bool bad = false;
-    for (int i = threadIdx.x; i < kCorner * kCorner; i += 256) {
-        const int r = i / kCorner, cidx = i % kCorner;
-        if (r >= M || cidx >= N) continue;
-        const float v = (float)D[(int64_t)r * ldd + cidx];
-        if (!compare) {
-            ref[i] = v;
-        } else {
-            const float d = fabsf(v - ref[i]);
-            bad = bad || !(d == d) || !(v == v);
-            md = fmaxf(md, d == d ? d : 0.f);
-            mr = fmaxf(mr, fabsf(ref[i]));
+// ---- numerical check of a tuning candidate: its WHOLE output against a plain fp32-accumulating product of the same
+// operands computed here (round 2 found exhaustive-mode algorithms that run without an error status and return wrong
+// numbers; round 3 found heuristic answers for 1024 x N x 64 that leave most of the output unwritten once the workspace
+// holds another product's data - and whose first 64 columns are right).  So the candidate runs twice on an output
+// filled with NaN patterns, first over a workspace filled with 0xFF, then over whatever it left there, and every element
+// of both results has to agree with the reference.
+__global__ __launch_bounds__(256) void ref_gemm(int ta, int tb, int M, int N, int K, const __bf16 *__restrict__ A, int64_t lda,
+                                                const __bf16 *__restrict__ B, int64_t ldb, const void *__restrict__ bias,
+                                                int bias32, float *__restrict__ ref) {
+    __shared__ float sa[16][65], sb[16][65];
+    const int tm = blockIdx.y * 64, tn = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int i = threadIdx.x; i < 1024; i += 256) {
+            // the operand's contiguous dimension runs along the lanes
+            const int ma = ta ? (i & 63) : (i >> 4), ka = ta ? (i >> 6) : (i & 15);
+            const int m = tm + ma, k = k0 + ka;
+            sa[ka][ma] = (m < M && k < K) ? (float)(ta ? A[(int64_t)k * lda + m] : A[(int64_t)m * lda + k]) : 0.f;
+            const int nb = tb ? (i >> 4) : (i & 63), kb = tb ? (i & 15) : (i >> 6);
+            const int n = tn + nb, k2 = k0 + kb;
+            sb[kb][nb] = (n < N && k2 < K) ? (float)(tb ? B[(int64_t)n * ldb + k2] : B[(int64_t)k2 * ldb + n]) : 0.f;
         }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = sa[kk][ty * 4 + i];
+                b[i] = sb[kk][tx * 4 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * b[j];
+        }
+        __syncthreads();
     }
-    if (compare) {      // non-negative floats order like their bit patterns
-        atomicMax(out2, __float_as_uint(bad ? INFINITY : md));
-        atomicMax(out2 + 1, __float_as_uint(mr));
-    }
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            const int m = tm + ty * 4 + i, n = tn + tx * 4 + j;
+            if (m >= M || n >= N) continue;
+            float v = acc[i][j];
+            if (bias) v += bias32 ? ((const float *)bias)[n] : (float)((const __bf16 *)bias)[n];
+            ref[(int64_t)m * N + n] = v;
+        }
 }
 
-// -> true if the output now in c.D agrees with the reference corner (or, with `record`, stores it as the reference)
-bool corner_check(State &S, const Call &c, bool record) {
-    if (!S.probe && hipMalloc(&S.probe, (kCorner * kCorner + 2) * sizeof(float)) != hipSuccess) return true;      // cannot check: accept
-    float *ref = (float *)S.probe;
-    unsigned *out2 = (unsigned *)(ref + kCorner * kCorner);
-    if (!record && hipMemsetAsync(out2, 0, 8, c.st) != hipSuccess) return true;
-    if (c.k.d32)
-        hipLaunchKernelGGL(corner_probe<float>, dim3(1), dim3(256), 0, c.st, (const float *)c.D, c.k.ldd, (int)c.k.M, (int)c.k.N, ref,
-                           out2, record ? 0 : 1);
-    else
-        hipLaunchKernelGGL(corner_probe<__bf16>, dim3(1), dim3(256), 0, c.st, (const __bf16 *)c.D, c.k.ldd, (int)c.k.M, (int)c.k.N,
-                           ref, out2, record ? 0 : 1);
-    if (record) return true;
-    float h[2] = {0.f, 0.f};
-    if (hipMemcpyAsync(h, out2, 8, hipMemcpyDeviceToHost, c.st) != hipSuccess || hipStreamSynchronize(c.st) != hipSuccess) return true;
-    // same operands, fp32 accumulation in a different order, bf16 or fp32 result: 2^-6 of the corner's largest value is
-    // far above any legitimate difference and far below a wrong tile
-    return h[0] <= 0.015625f * fmaxf(h[1], 1e-20f);
+template <typename OT>
+__global__ __launch_bounds__(256) void full_compare(const OT *__restrict__ D, int64_t ldd, int64_t MN, int N,
+                                                    const float *__restrict__ ref, unsigned *__restrict__ out2) {
+    float md = 0.f, mr = 0.f;
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < MN; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / N;
+        const float v = (float)D[r * ldd + (i - r * N)], w = ref[i];
+        const float d = fabsf(v - w);
+        bad = bad || !(d == d);
+        md = fmaxf(md, d == d ? d : 0.f);
+        mr = fmaxf(mr, fabsf(w));
+    }
+    // non-negative floats order like their bit patterns
+    if (bad || md > 0.f) atomicMax(out2, __float_as_uint(bad ? INFINITY : md));
+    if (mr > 0.f) atomicMax(out2 + 1, __float_as_uint(mr));
+}
+
+// The reference product of this call as M x N fp32 (device memory the caller frees), nullptr if it cannot be had.
+float *make_reference(const Call &c) {
+    const Key &k = c.k;
+    if (k.M > (64 << 16) || k.N > (int64_t)INT32_MAX || k.K > (int64_t)INT32_MAX) return nullptr;
+    float *ref = nullptr;
+    if (hipMalloc((void **)&ref, (size_t)k.M * k.N * sizeof(float)) != hipSuccess) return nullptr;
+    hipLaunchKernelGGL(ref_gemm, dim3((unsigned)((k.N + 63) / 64), (unsigned)((k.M + 63) / 64)), dim3(256), 0, c.st, k.ta, k.tb,
+                       (int)k.M, (int)k.N, (int)k.K, (const __bf16 *)c.A, k.lda, (const __bf16 *)c.B, k.ldb, c.bias, k.bias32, ref);
+    if (hipGetLastError() != hipSuccess) {
+        (void)hipFree(ref);
+        return nullptr;
+    }
+    return ref;
+}
+
+hipblasStatus_t run(State &S, const Call &c, Problem &p, const hipblasLtMatmulAlgo_t &algo, size_t ws_need, int split);
+
+// -> true if the algorithm reproduces the reference on NaN-filled output, over a poisoned and over a used workspace
+bool validate(State &S, const Call &c, Problem &p, const hipblasLtMatmulAlgo_t &algo, size_t ws_need, int split, const float *ref) {
+    if (!ref) return true;                                                                           // cannot check: accept
+    if (!S.probe && hipMalloc(&S.probe, 2 * sizeof(unsigned)) != hipSuccess) return true;
+    unsigned *out2 = (unsigned *)S.probe;
+    const Key &k = c.k;
+    const size_t es = k.d32 ? 4 : 2;
+    const int64_t MN = k.M * k.N;
+    const unsigned blocks = (unsigned)std::min<int64_t>(4096, (MN + 255) / 256);
+    if (c.ws_bytes && hipMemsetAsync(c.ws, 0xFF, c.ws_bytes, c.st) != hipSuccess) return true;
+    for (int pass = 0; pass < 2; ++pass) {
+        if (hipMemsetAsync(out2, 0, 8, c.st) != hipSuccess) return true;
+        if (hipMemset2DAsync(c.D, (size_t)k.ldd * es, 0xFF, (size_t)k.N * es, (size_t)k.M, c.st) != hipSuccess) return true;
+        if (run(S, c, p, algo, ws_need, split) != HIPBLAS_STATUS_SUCCESS) return false;
+        if (k.d32)
+            hipLaunchKernelGGL(full_compare<float>, dim3(blocks), dim3(256), 0, c.st, (const float *)c.D, k.ldd, MN, (int)k.N, ref, out2);
+        else
+            hipLaunchKernelGGL(full_compare<__bf16>, dim3(blocks), dim3(256), 0, c.st, (const __bf16 *)c.D, k.ldd, MN, (int)k.N, ref, out2);
+        float h[2] = {0.f, 0.f};
+        if (hipMemcpyAsync(h, out2, 8, hipMemcpyDeviceToHost, c.st) != hipSuccess || hipStreamSynchronize(c.st) != hipSuccess) return true;
+        // same operands, fp32 accumulation in a different order, bf16 or fp32 result: 2^-6 of the largest value is far
+        // above any legitimate difference and far below a wrong or missing tile
+        if (!(h[0] <= 0.015625f * fmaxf(h[1], 1e-20f))) return false;
+    }
+    return true;
 }
 
 hipblasStatus_t run(State &S, const Call &c, Problem &p, const hipblasLtMatmulAlgo_t &algo, size_t ws_need, int split) {
@@ -341,6 +405,10 @@ hipblasStatus_t choose_for_split(State &S, const Call &c, Problem &p, int split,
     }
     out.split = split;
     if (S.mode == 0 || (cand.size() == 1 && !must_time)) {
+        if (!validate(S, c, p, cand[0].algo, cand[0].workspaceSize, split, c.ref)) {
+            ++S.rejected;
+            return HIPBLAS_STATUS_EXECUTION_FAILED;
+        }
         out.algo = cand[0].algo;
         out.workspace = cand[0].workspaceSize;
         out.index = hipblaslt_ext::getIndexFromAlgo(out.algo);
@@ -351,22 +419,22 @@ hipblasStatus_t choose_for_split(State &S, const Call &c, Problem &p, int split,
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return HIPBLAS_STATUS_ALLOC_FAILED;
     float best = -1.f;
     size_t best_i = 0;
-    // the yardstick of the candidate check: what the heuristic's first answer for the UNSPLIT problem computes
-    // (recorded once per problem by choose(); here only compared)
-    // coarse pass over everything, then a longer look at the best few
+    // coarse pass over everything, then a longer look at the fastest few THAT COMPUTE THE REFERENCE's NUMBERS (walked in
+    // order of speed: an algorithm that skips part of the output is fast)
     std::vector<std::pair<float, size_t>> timed;
     for (size_t i = 0; i < cand.size(); ++i) {
         const float us = time_algo(S, c, p, cand[i].algo, cand[i].workspaceSize, split, e0, e1, 3);
-        if (us <= 0.f) continue;
-        if (c.check && !corner_check(S, c, false)) {        // ran, but not to the same numbers: never a candidate
+        if (us > 0.f) timed.emplace_back(us, i);
+    }
+    std::sort(timed.begin(), timed.end());
+    int looked = 0;
+    for (size_t j = 0; j < timed.size() && looked < 4; ++j) {
+        const size_t i = timed[j].second;
+        if (!validate(S, c, p, cand[i].algo, cand[i].workspaceSize, split, c.ref)) {
             ++S.rejected;
             continue;
         }
-        timed.emplace_back(us, i);
-    }
-    std::sort(timed.begin(), timed.end());
-    for (size_t j = 0; j < std::min<size_t>(timed.size(), 4); ++j) {
-        const size_t i = timed[j].second;
+        ++looked;
         const float us = time_algo(S, c, p, cand[i].algo, cand[i].workspaceSize, split, e0, e1, 20);
         if (us > 0.f && (best < 0.f || us < best)) {
             best = us;
@@ -404,24 +472,8 @@ hipblasStatus_t choose(State &S, const Call &call, Choice &out) {
     Call c = call;                       // candidates are timed without the piggy-backed finalize job
     c.fin_part = nullptr;
     const std::vector<int> splits = split_candidates(S, c);
-    if (S.mode != 0) {
-        // reference for the candidate check: the heuristic's first answer on the unsplit problem
-        Problem p0;
-        if (make_problem(c, p0, 1) == HIPBLAS_STATUS_SUCCESS) {
-            hipblasLtMatmulPreference_t pref = nullptr;
-            if (hipblasLtMatmulPreferenceCreate(&pref) == HIPBLAS_STATUS_SUCCESS) {
-                const uint64_t wsmax = c.ws_bytes;
-                hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsmax, sizeof(wsmax));
-                hipblasLtMatmulHeuristicResult_t first;
-                int got = 0;
-                if (hipblasLtMatmulAlgoGetHeuristic(S.handle, p0.desc, p0.la, p0.lb, p0.ld, p0.ld, pref, 1, &first, &got) ==
-                        HIPBLAS_STATUS_SUCCESS && got == 1 &&
-                    run(S, c, p0, first.algo, first.workspaceSize, 1) == HIPBLAS_STATUS_SUCCESS)
-                    c.check = corner_check(S, c, true);
-                hipblasLtMatmulPreferenceDestroy(pref);
-            }
-        }
-    }
+    float *ref = S.mode != 0 ? make_reference(c) : nullptr;
+    c.ref = ref;
     hipblasStatus_t last = HIPBLAS_STATUS_NOT_SUPPORTED;
     bool have = false;
     for (int split : splits) {
@@ -435,6 +487,10 @@ hipblasStatus_t choose(State &S, const Call &call, Choice &out) {
         }
         if (!have || (ch.us > 0.f && ch.us < out.us)) out = ch;
         have = true;
+    }
+    if (ref) {
+        (void)hipStreamSynchronize(c.st);
+        (void)hipFree(ref);
     }
     return have ? HIPBLAS_STATUS_SUCCESS : last;
 }
@@ -450,6 +506,19 @@ bool resolve(State &S, const Call &c, Problem &p, Choice &ch) {
     if (hipblaslt_ext::matmulIsAlgoSupported(S.handle, p.desc, &one, p.la, p.lb, &zero, p.ld, p.ld, res[0].algo, need) !=
             HIPBLAS_STATUS_SUCCESS || need + partial_bytes(c.k, ch.split) > c.ws_bytes)
         return false;
+    // an entry is only as good as the build and the workspace use it was tuned with: hold it to the reference once
+    Call cc = c;
+    cc.fin_part = nullptr;
+    float *ref = make_reference(cc);
+    const bool ok = validate(S, cc, p, res[0].algo, need, ch.split, ref);
+    if (ref) {
+        (void)hipStreamSynchronize(c.st);
+        (void)hipFree(ref);
+    }
+    if (!ok) {
+        ++S.rejected;
+        return false;
+    }
     ch.algo = res[0].algo;
     ch.workspace = need;
     ch.resolved = true;

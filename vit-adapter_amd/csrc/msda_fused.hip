@@ -90,7 +90,7 @@ struct TapF {           // one sampling tap as the 8 channel lanes of a row read
 template <typename VT, typename PT, int L, int P>
 __global__ __launch_bounds__(kBlock) void msda_fused_fwd(
     const VT *__restrict__ value, const int64_t *__restrict__ shapes, const int64_t *__restrict__ lsi,
-    const PT *__restrict__ off, const PT *__restrict__ logit, const float *__restrict__ ref,
+    const PT *__restrict__ off, const PT *__restrict__ logit, int64_t os, int64_t ls, const float *__restrict__ ref,
     int ref_levels, int64_t S, int M, int64_t Lq, int64_t total_rows, int64_t nblocks,
     VT *__restrict__ out) {
     constexpr int LP = L * P;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(kBlock) void msda_fused_fwd(
         if (w < total_rows && lv.valid) {
             const int64_t q = w % Lq;
             const int64_t rw = (w / Lq / M * Lq + q) * M + (w / Lq) % M;
-            const float2 o = load2(off + (rw * LP + sidx) * 2);
+            const float2 o = load2(off + rw * os + sidx * 2);
             const float2 rp = *reinterpret_cast<const float2 *>(ref + (q * ref_levels + (ref_levels > 1 ? l : 0)) * 2);
             const Tap<float> t = make_tap<float>(rp.x + o.x / (float)lv.W, rp.y + o.y / (float)lv.H, lv.H, lv.W);
 #pragma unroll
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(kBlock) void msda_fused_fwd(
     const VT *vhead = value + n * S * stride + m * kD + sub * 4;
 
     float p[LP];
-    row_softmax<PT, LP>(logit + row * LP, p);
+    row_softmax<PT, LP>(logit + row * ls, p);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int l = 0; l < L; ++l) {
@@ -406,6 +406,7 @@ struct FusedArgs {
     void *out;
     float *grad_value;
     void *d_off, *d_logit;
+    int64_t os = 0, ls = 0;          // forward only: elements between the offsets / logits of consecutive rows
     bool taps_only = false;          // d(offsets), d(logits) only: grad_value belongs to the tile pass (msda_tile.hip)
     hipStream_t st;
 };
@@ -417,8 +418,8 @@ int launch_fwd(const FusedArgs &a) {
     const int64_t grid = (nblocks + 7) / 8 * 8;
     if (grid >= ((int64_t)1 << 31)) return fail(VAH_E_SHAPE, "msda fused forward: grid too large");
     hipLaunchKernelGGL((msda_fused_fwd<VT, PT, L, P>), dim3((unsigned)grid), dim3(kBlock), 0, a.st,
-                       (const VT *)a.value, a.shapes, a.lsi, (const PT *)a.off, (const PT *)a.logit, a.ref,
-                       a.ref_levels, a.S, (int)a.M, a.Lq, rows, nblocks, (VT *)a.out);
+                       (const VT *)a.value, a.shapes, a.lsi, (const PT *)a.off, (const PT *)a.logit, a.os ? a.os : L * P * 2,
+                       a.ls ? a.ls : L * P, a.ref, a.ref_levels, a.S, (int)a.M, a.Lq, rows, nblocks, (VT *)a.out);
     return check_launch("msda fused forward launch");
 }
 
@@ -500,7 +501,8 @@ int vah_msda_fused_supported(int64_t D, int64_t L, int64_t P) {
 }
 
 int vah_msda_fused_forward(const void *value, int value_dtype, const int64_t *shapes, const int64_t *lsi,
-                           const void *offsets, const void *logits, int param_dtype, const float *ref,
+                           const void *offsets, const void *logits, int param_dtype, int64_t offsets_stride,
+                           int64_t logits_stride, const float *ref,
                            int64_t ref_levels, int64_t N, int64_t S, int64_t M, int64_t D, int64_t L,
                            int64_t Lq, int64_t P, void *out, void *stream) {
     using namespace vah;
@@ -513,6 +515,10 @@ int vah_msda_fused_forward(const void *value, int value_dtype, const int64_t *sh
     FusedArgs a{};
     a.value = value, a.off = offsets, a.logit = logits, a.shapes = shapes, a.lsi = lsi, a.ref = ref;
     a.ref_levels = (int)ref_levels, a.N = N, a.S = S, a.M = M, a.L = L, a.Lq = Lq, a.P = P, a.out = out;
+    a.os = offsets_stride, a.ls = logits_stride;
+    if (offsets_stride < 0 || logits_stride < 0 || ((offsets_stride * (param_dtype == 1 ? 2 : 4)) % 8) ||
+        ((logits_stride * (param_dtype == 1 ? 2 : 4)) % (param_dtype == 1 ? 2 : 4)))
+        return fail(VAH_E_ALIGN, "%s: bad strides", fn);
     a.st = (hipStream_t)stream;
     // algorithmic bytes the launch really moves: value / out in the value dtype, offsets (2) + logits (1)
     // per sample in the parameter dtype; the op's fp32 definition is reported

@@ -4,8 +4,8 @@
 //
 // Same arithmetic as msda_fused_fwd (softmax over the P logits, loc = ref + off / (W, H), bilinear gather:
 // spec ms_deform_im2col_cuda.cuh:33-84, 237-299); what changes is who does what:
-//   * the queries are grouped by the 8 x 8-pixel tile of the value map their reference point falls in (host
-//     schedule, static per reference grid: `perm`, `group_off`, `gwin`); a workgroup = (batch n, group, head m)
+//   * the queries are grouped by the 8 x 8-pixel tile of the value map their reference point falls in (schedule built
+//     on the device by msda_win_schedule: no host copy of the geometry); a workgroup walks (batch n, group, head m) items,
 //     stages the group's value window - the tile + `halo` + 1 pixels on every side, 64-byte rows of one head -
 //     in LDS ONCE (~20 x 20 rows, 25 KB) and every one of the group's ~336 queries reads its 16 corner rows
 //     from there: 12x reuse of a row instead of 12 passes through L2;
@@ -52,127 +52,225 @@ __device__ __forceinline__ void axpy_row(float (&acc)[kD], float w, const unsign
     }
 }
 
-struct GroupWin {       // per group: window origin and size in pixels of the level
-    int y0, x0, h, w;
+// ---- the schedule, built on the device -------------------------------------------------------------------------
+// Workspace: header (16 ints), group_off[G + 1], cursor / count[G], perm[Lq].  Round 2 built perm / group_off / windows
+// on the HOST from a D2H copy of spatial_shapes, cached by tensor identity: a sync per forward for callers that make
+// fresh shape tensors every call (the reference's deform_inputs does, adapter_modules.py:28-47), and impossible to
+// capture in a HIP graph.  Now ONE 1024-thread workgroup counts the queries per 8 x 8-pixel group of the value map
+// (LDS counters up to 4096 groups, global ones beyond), scans the counts and writes the permutation; the level geometry
+// is read from the device tensors.  The order of the queries inside a group does not matter (every row is computed on
+// its own).
+struct WinHeader {
+    int valid, H, W, ntx, nty, G, pad0, pad1;
+    long long start;
+    int pad2[6];
 };
+static_assert(sizeof(WinHeader) == 64, "header");
+constexpr int kTile = 8;
+constexpr int kSchedThreads = 1024;
+constexpr int kLdsGroups = 4096;
 
+__device__ __forceinline__ int group_of(float rx, float ry, int H, int W, int ntx, int nty) {
+    const int ty = min(max((int)floorf(ry * (float)H / (float)kTile), 0), nty - 1);
+    const int tx = min(max((int)floorf(rx * (float)W / (float)kTile), 0), ntx - 1);
+    return ty * ntx + tx;
+}
+
+__global__ __launch_bounds__(kSchedThreads) void msda_win_schedule(const float *__restrict__ ref, const int64_t *__restrict__ shapes,
+                                                                   const int64_t *__restrict__ lsi, int Lq, int64_t S, int Gmax,
+                                                                   unsigned char *__restrict__ ws) {
+    __shared__ int s_cnt[kLdsGroups];
+    __shared__ int s_scan[kSchedThreads];
+    const Level lv = read_level(shapes, lsi, 0, S);
+    WinHeader *hd = reinterpret_cast<WinHeader *>(ws);
+    int *group_off = reinterpret_cast<int *>(ws + sizeof(WinHeader));
+    int *cursor = group_off + Gmax + 1;
+    int *perm = cursor + Gmax;
+    const int ntx = lv.valid ? (lv.W + kTile - 1) / kTile : 1, nty = lv.valid ? (lv.H + kTile - 1) / kTile : 1;
+    const int G = ntx * nty;
+    const bool ok = lv.valid && G <= Gmax;
+    if (threadIdx.x == 0) {
+        WinHeader h{};
+        h.valid = ok, h.H = lv.H, h.W = lv.W, h.ntx = ntx, h.nty = nty, h.G = ok ? G : 0, h.start = lv.start;
+        *hd = h;
+    }
+    if (!ok) return;
+    const bool lds = G <= kLdsGroups;
+    int *cnt = lds ? s_cnt : cursor;
+    for (int i = threadIdx.x; i < G; i += kSchedThreads) cnt[i] = 0;
+    __syncthreads();
+    for (int q = threadIdx.x; q < Lq; q += kSchedThreads) {
+        const float2 rp = *reinterpret_cast<const float2 *>(ref + (int64_t)q * 2);
+        atomicAdd(&cnt[group_of(rp.x, rp.y, lv.H, lv.W, ntx, nty)], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the G counts: each thread takes a contiguous slice
+    const int per = (G + kSchedThreads - 1) / kSchedThreads;
+    const int b0 = min((int)threadIdx.x * per, G), b1 = min(b0 + per, G);
+    int sum = 0;
+    for (int i = b0; i < b1; ++i) sum += cnt[i];
+    s_scan[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < kSchedThreads; d <<= 1) {
+        const int v = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0;
+        __syncthreads();
+        s_scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = s_scan[threadIdx.x] - sum;
+    for (int i = b0; i < b1; ++i) {
+        const int c = cnt[i];
+        group_off[i] = run;
+        cnt[i] = run;                       // becomes the group's write cursor
+        run += c;
+    }
+    if (threadIdx.x == kSchedThreads - 1) group_off[G] = s_scan[kSchedThreads - 1];
+    __syncthreads();
+    for (int q = threadIdx.x; q < Lq; q += kSchedThreads) {
+        const float2 rp = *reinterpret_cast<const float2 *>(ref + (int64_t)q * 2);
+        perm[atomicAdd(&cnt[group_of(rp.x, rp.y, lv.H, lv.W, ntx, nty)], 1)] = q;
+    }
+}
+
+// os / ls: elements between the offsets / logits of consecutive (n, q, m) rows (contiguous tensors: 8 and 4; the module's
+// interleaved fp32 [offsets | logits] rows: 12 and 12)
 template <typename VT, typename PT>
 __global__ __launch_bounds__(kWinThreads) void msda_fused_fwd_win(
-    const VT *__restrict__ value, const PT *__restrict__ off, const PT *__restrict__ logit, const float *__restrict__ ref,
-    const int *__restrict__ perm, const int *__restrict__ group_off, const GroupWin *__restrict__ gwin, int H, int W,
-    int64_t start, int64_t S, int M, int64_t Lq, int ngroups, int64_t nblocks, VT *__restrict__ out) {
+    const VT *__restrict__ value, const PT *__restrict__ off, const PT *__restrict__ logit, int64_t os, int64_t ls,
+    const float *__restrict__ ref, const unsigned char *__restrict__ ws, int Gmax, int halo, int64_t S, int M, int N, int64_t Lq,
+    VT *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char Vs[];
     constexpr int ROWB = kD * (int)sizeof(VT);
     constexpr int PCS = ROWB / 16;
-    const int64_t blk = xcd_chunked_block(nblocks);
-    if (blk >= nblocks) return;
-    const int m = (int)(blk % M);
-    const int g = (int)((blk / M) % ngroups);
-    const int64_t n = blk / M / ngroups;
-    const GroupWin gw = gwin[g];
-    const int64_t stride = (int64_t)M * kD;
-    const VT *vmap = value + (n * S + start) * stride + m * kD;
-    // ---- the window: whole 64 / 128-byte rows, 16 bytes per lane and load
-    for (int i = threadIdx.x; i < gw.h * gw.w * PCS; i += kWinThreads) {
-        const int wp = i / PCS, pc = i - wp * PCS;
-        const int wy = wp / gw.w, wx = wp - wy * gw.w;
-        *reinterpret_cast<uint4 *>(Vs + wp * ROWB + 16 * pc) = *reinterpret_cast<const uint4 *>(
-            reinterpret_cast<const unsigned char *>(vmap + ((int64_t)(gw.y0 + wy) * W + gw.x0 + wx) * stride) + 16 * pc);
-    }
-    __syncthreads();
-    const int beg = group_off[g], end = group_off[g + 1];
-    for (int idx = beg + threadIdx.x; idx < end; idx += kWinThreads) {
-        const int64_t q = perm[idx];
-        const int64_t row = (n * Lq + q) * M + m;
-        // ---- the row's operands: 4 offsets (x, y), 4 logits, the reference point
-        uint32_t ow[kP * 2 * sizeof(PT) / 4], lw[kP * sizeof(PT) / 4];
-        {
-            const uint4 *op = reinterpret_cast<const uint4 *>(off + row * kP * 2);
-#pragma unroll
-            for (int i = 0; i < (int)(kP * 2 * sizeof(PT) / 16); ++i) {
-                const uint4 v = op[i];
-                ow[4 * i] = v.x, ow[4 * i + 1] = v.y, ow[4 * i + 2] = v.z, ow[4 * i + 3] = v.w;
-            }
-            const uint2 *lp = reinterpret_cast<const uint2 *>(logit + row * kP);
-#pragma unroll
-            for (int i = 0; i < (int)(kP * sizeof(PT) / 8); ++i) {
-                const uint2 v = lp[i];
-                lw[2 * i] = v.x, lw[2 * i + 1] = v.y;
-            }
+    const WinHeader &hd = *reinterpret_cast<const WinHeader *>(ws);
+    const int *group_off = reinterpret_cast<const int *>(ws + sizeof(WinHeader));
+    const int *perm = group_off + Gmax + 1 + Gmax;
+    const int H = hd.H, W = hd.W, G = hd.G;
+    const int64_t start = hd.start;
+    const int64_t items = (int64_t)N * G * M;
+    // work items (n, group, head), heads of a group adjacent; XCD b % 8 walks a contiguous eighth
+    const int64_t per = (items + 7) / 8;
+    for (int64_t it = (int64_t)(blockIdx.x / 8); it < per; it += gridDim.x / 8) {
+        const int64_t blk = (int64_t)(blockIdx.x % 8) * per + it;
+        if (blk >= items) break;
+        const int m = (int)(blk % M);
+        const int g = (int)((blk / M) % G);
+        const int64_t n = blk / M / G;
+        const int gy = g / hd.ntx, gx = g - gy * hd.ntx;
+        // the window: the tile + halo + 1 pixels on every side, clipped to the map
+        const int wy0 = max(gy * kTile - halo - 1, 0), wx0 = max(gx * kTile - halo - 1, 0);
+        const int wh = min(gy * kTile + kTile + halo + 1, H) - wy0, ww = min(gx * kTile + kTile + halo + 1, W) - wx0;
+        const int64_t stride = (int64_t)M * kD;
+        const VT *vmap = value + (n * S + start) * stride + m * kD;
+        __syncthreads();                    // the previous item's readers are done with Vs
+        // ---- the window: whole 64 / 128-byte rows, 16 bytes per lane and load
+        for (int i = threadIdx.x; i < wh * ww * PCS; i += kWinThreads) {
+            const int wp = i / PCS, pc = i - wp * PCS;
+            const int wy = wp / ww, wx = wp - wy * ww;
+            *reinterpret_cast<uint4 *>(Vs + wp * ROWB + 16 * pc) = *reinterpret_cast<const uint4 *>(
+                reinterpret_cast<const unsigned char *>(vmap + ((int64_t)(wy0 + wy) * W + wx0 + wx) * stride) + 16 * pc);
         }
-        const float2 rp = *reinterpret_cast<const float2 *>(ref + q * 2);
-        float a[kP];
-        {
-            float mx = -INFINITY, sum = 0.f;
+        __syncthreads();
+        const int beg = group_off[g], end = group_off[g + 1];
+        for (int idx = beg + threadIdx.x; idx < end; idx += kWinThreads) {
+            const int64_t q = perm[idx];
+            const int64_t row = (n * Lq + q) * M + m;
+            // ---- the row's operands: 4 offsets (x, y), 4 logits, the reference point
+            uint32_t ow[kP * 2 * sizeof(PT) / 4], lw[kP * sizeof(PT) / 4];
+            {
+                const uint4 *op = reinterpret_cast<const uint4 *>(off + row * os);
+#pragma unroll
+                for (int i = 0; i < (int)(kP * 2 * sizeof(PT) / 16); ++i) {
+                    const uint4 v = op[i];
+                    ow[4 * i] = v.x, ow[4 * i + 1] = v.y, ow[4 * i + 2] = v.z, ow[4 * i + 3] = v.w;
+                }
+                const uint2 *lp = reinterpret_cast<const uint2 *>(logit + row * ls);
+#pragma unroll
+                for (int i = 0; i < (int)(kP * sizeof(PT) / 8); ++i) {
+                    const uint2 v = lp[i];
+                    lw[2 * i] = v.x, lw[2 * i + 1] = v.y;
+                }
+            }
+            const float2 rp = *reinterpret_cast<const float2 *>(ref + q * 2);
+            float a[kP];
+            {
+                float mx = -INFINITY, sum = 0.f;
+#pragma unroll
+                for (int p = 0; p < kP; ++p) {
+                    a[p] = word_elem<PT>(lw, p);
+                    mx = fmaxf(mx, a[p]);
+                }
+#pragma unroll
+                for (int p = 0; p < kP; ++p) {
+                    a[p] = __expf(a[p] - mx);
+                    sum += a[p];
+                }
+                const float inv = 1.f / sum;
+#pragma unroll
+                for (int p = 0; p < kP; ++p) a[p] *= inv;
+            }
+            float acc[kD];
+#pragma unroll
+            for (int c = 0; c < kD; ++c) acc[c] = 0.f;
 #pragma unroll
             for (int p = 0; p < kP; ++p) {
-                a[p] = word_elem<PT>(lw, p);
-                mx = fmaxf(mx, a[p]);
+                // the same expressions as msda_fused_fwd: ref + off / W, then make_tap's arithmetic
+                const float lx = rp.x + word_elem<PT>(ow, 2 * p) / (float)W, ly = rp.y + word_elem<PT>(ow, 2 * p + 1) / (float)H;
+                const float h_im = ly * (float)H - 0.5f, w_im = lx * (float)W - 0.5f;
+                const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
+                const float hs = inside ? h_im : 0.f, wsx = inside ? w_im : 0.f;
+                const float hf = floorf(hs), wf = floorf(wsx);
+                const int y0 = (int)hf, x0 = (int)wf;
+                const float lh = hs - hf, lwt = wsx - wf, hh = 1.f - lh, hw = 1.f - lwt;
+                const float cw[4] = {hh * hw, hh * lwt, lh * hw, lh * lwt};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int yy = y0 + (c >> 1), xx = x0 + (c & 1);
+                    const bool valid = inside && yy >= 0 && yy <= H - 1 && xx >= 0 && xx <= W - 1;
+                    const int wy = yy - wy0, wx = xx - wx0;
+                    const bool inwin = valid && (unsigned)wy < (unsigned)wh && (unsigned)wx < (unsigned)ww;
+                    const float wgt = a[p] * cw[c];
+                    axpy_row<VT>(acc, inwin ? wgt : 0.f, Vs + (inwin ? wy * ww + wx : 0) * ROWB);
+                    if (valid && !inwin)           // beyond the halo: this lane fetches the row itself
+                        axpy_row<VT>(acc, wgt, reinterpret_cast<const unsigned char *>(vmap + ((int64_t)yy * W + xx) * stride));
+                }
             }
+            VT *dst = out + row * kD;
+            if constexpr (std::is_same<VT, float>::value) {
 #pragma unroll
-            for (int p = 0; p < kP; ++p) {
-                a[p] = __expf(a[p] - mx);
-                sum += a[p];
-            }
-            const float inv = 1.f / sum;
+                for (int c = 0; c < kD; c += 4) *reinterpret_cast<float4 *>(dst + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
+            } else {
 #pragma unroll
-            for (int p = 0; p < kP; ++p) a[p] *= inv;
-        }
-        float acc[kD];
+                for (int c = 0; c < kD; c += 8) {
+                    bf16x8 o;
 #pragma unroll
-        for (int c = 0; c < kD; ++c) acc[c] = 0.f;
-#pragma unroll
-        for (int p = 0; p < kP; ++p) {
-            // the same expressions as msda_fused_fwd: ref + off / W, then make_tap's arithmetic
-            const float lx = rp.x + word_elem<PT>(ow, 2 * p) / (float)W, ly = rp.y + word_elem<PT>(ow, 2 * p + 1) / (float)H;
-            const float h_im = ly * (float)H - 0.5f, w_im = lx * (float)W - 0.5f;
-            const bool inside = h_im > -1.f && w_im > -1.f && h_im < (float)H && w_im < (float)W;
-            const float hs = inside ? h_im : 0.f, ws = inside ? w_im : 0.f;
-            const float hf = floorf(hs), wf = floorf(ws);
-            const int y0 = (int)hf, x0 = (int)wf;
-            const float lh = hs - hf, lwt = ws - wf, hh = 1.f - lh, hw = 1.f - lwt;
-            const float cw[4] = {hh * hw, hh * lwt, lh * hw, lh * lwt};
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const int yy = y0 + (c >> 1), xx = x0 + (c & 1);
-                const bool valid = inside && yy >= 0 && yy <= H - 1 && xx >= 0 && xx <= W - 1;
-                const int wy = yy - gw.y0, wx = xx - gw.x0;
-                const bool inwin = valid && (unsigned)wy < (unsigned)gw.h && (unsigned)wx < (unsigned)gw.w;
-                const float wgt = a[p] * cw[c];
-                axpy_row<VT>(acc, inwin ? wgt : 0.f, Vs + (inwin ? wy * gw.w + wx : 0) * ROWB);
-                if (valid && !inwin)           // beyond the halo: this lane fetches the row itself
-                    axpy_row<VT>(acc, wgt, reinterpret_cast<const unsigned char *>(vmap + ((int64_t)yy * W + xx) * stride));
-            }
-        }
-        VT *dst = out + row * kD;
-        if constexpr (std::is_same<VT, float>::value) {
-#pragma unroll
-            for (int c = 0; c < kD; c += 4) *reinterpret_cast<float4 *>(dst + c) = make_float4(acc[c], acc[c + 1], acc[c + 2], acc[c + 3]);
-        } else {
-#pragma unroll
-            for (int c = 0; c < kD; c += 8) {
-                bf16x8 o;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[c + e];
-                *reinterpret_cast<bf16x8 *>(dst + c) = o;
+                    for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[c + e];
+                    *reinterpret_cast<bf16x8 *>(dst + c) = o;
+                }
             }
         }
     }
 }
 
+int64_t win_gmax(int64_t S) { return S / 8 + 2; }        // groups of 8 x 8 pixels of an H x W map with H * W <= S: at W = 1, H / 8 + 1
+
 template <typename VT, typename PT>
-int launch(const void *value, const void *off, const void *logit, const float *ref, const int *perm, const int *group_off,
-           const int *gwin, int H, int W, int64_t start, int64_t N, int64_t S, int64_t M, int64_t Lq, int ngroups, int max_win_px,
-           void *out, hipStream_t st) {
-    const int64_t nblocks = N * ngroups * M;
-    const int64_t grid = (nblocks + 7) / 8 * 8;
-    if (grid >= ((int64_t)1 << 31)) return fail(VAH_E_SHAPE, "msda fused forward (windows): grid too large");
-    const int smem = max_win_px * kD * (int)sizeof(VT);
-    if (smem > 64 * 1024) return fail(VAH_E_SHAPE, "msda fused forward (windows): window of %d pixels too large", max_win_px);
+int launch(const void *value, const void *off, const void *logit, int64_t os, int64_t ls, const float *ref, const int64_t *shapes,
+           const int64_t *lsi, int64_t N, int64_t S, int64_t M, int64_t Lq, int halo, void *ws, void *out, hipStream_t st) {
+    const int Gmax = (int)win_gmax(S);
+    hipLaunchKernelGGL(msda_win_schedule, dim3(1), dim3(kSchedThreads), 0, st, ref, shapes, lsi, (int)Lq, S, Gmax, (unsigned char *)ws);
+    if (int rc = check_launch("msda window schedule launch")) return rc;
+    const int side = kTile + 2 * (halo + 1);
+    const int smem = side * side * kD * (int)sizeof(VT);
+    if (smem > 64 * 1024) return fail(VAH_E_SHAPE, "msda fused forward (windows): a halo of %d pixels needs too much LDS", halo);
     if (int rc = allow_dynamic_lds((const void *)msda_fused_fwd_win<VT, PT>, smem, "msda fused forward (windows)")) return rc;
+    // as many workgroups as there can be items, up to a few per CU slot: the kernel loops over the actual items
+    int64_t grid = N * M * Gmax;
+    if (grid > 16384) grid = 16384;
+    grid = (grid + 7) / 8 * 8;
     hipLaunchKernelGGL((msda_fused_fwd_win<VT, PT>), dim3((unsigned)grid), dim3(kWinThreads), smem, st, (const VT *)value,
-                       (const PT *)off, (const PT *)logit, ref, perm, group_off, (const GroupWin *)gwin, H, W, start, S, (int)M, Lq,
-                       ngroups, nblocks, (VT *)out);
+                       (const PT *)off, (const PT *)logit, os, ls, ref, (const unsigned char *)ws, Gmax, halo, S, (int)M, (int)N, Lq,
+                       (VT *)out);
     return check_launch("msda fused forward (windows) launch");
 }
 
@@ -181,29 +279,42 @@ int launch(const void *value, const void *off, const void *logit, const float *r
 
 extern "C" {
 
-int vah_msda_fused_forward_win(const void *value, int value_dtype, const void *offsets, const void *logits, int param_dtype,
-                               const float *ref, const int32_t *perm, const int32_t *group_off, const int32_t *group_win,
-                               int64_t ngroups, int64_t max_win_px, int64_t H, int64_t W, int64_t level_start, int64_t N,
-                               int64_t S, int64_t M, int64_t D, int64_t Lq, int64_t P, void *out, void *stream) {
+int64_t vah_msda_win_ws_bytes(int64_t S, int64_t Lq) {
+    vah::clear_error();
+    if (S < 1 || Lq < 0 || Lq > (1 << 18) || S >= (1 << 24)) {
+        vah::fail(VAH_E_UNSUPPORTED, "vah_msda_win_ws_bytes: the window forward takes up to 2^18 queries of a level of up to 2^24 pixels");
+        return -1;
+    }
+    const int64_t g = vah::win_gmax(S);
+    return ((int64_t)sizeof(vah::WinHeader) + (2 * g + 1 + Lq) * 4 + 255) / 256 * 256;
+}
+
+int vah_msda_fused_forward_win(const void *value, int value_dtype, const int64_t *shapes, const int64_t *lsi, const void *offsets,
+                               const void *logits, int param_dtype, int64_t offsets_stride, int64_t logits_stride, const float *ref,
+                               int64_t N, int64_t S, int64_t M, int64_t D, int64_t Lq, int64_t P, int64_t halo, void *ws,
+                               int64_t ws_bytes, void *out, void *stream) {
     using namespace vah;
     clear_error();
     const char *fn = "vah_msda_fused_forward_win";
-    if (N < 0 || S < 1 || M < 1 || Lq < 0 || ngroups < 1 || H < 1 || W < 1 || level_start < 0 || level_start + H * W > S ||
-        max_win_px < 1 || M * D >= (1LL << 31) || Lq >= (1LL << 31))
-        return fail(VAH_E_SHAPE, "%s: bad dims", fn);
+    if (N < 0 || S < 1 || M < 1 || Lq < 0 || halo < 0 || halo > 32 || M * D >= (1LL << 31)) return fail(VAH_E_SHAPE, "%s: bad dims", fn);
     if (D != kD || P != kP) return fail(VAH_E_UNSUPPORTED, "%s: needs D == 32, P == 4 (one level)", fn);
     if (N * Lq * M == 0) return VAH_OK;
-    if (!value || !offsets || !logits || !ref || !perm || !group_off || !group_win || !out) return fail(VAH_E_NULL, "%s: null pointer", fn);
-    if (((uintptr_t)value | (uintptr_t)out | (uintptr_t)offsets) % 16 || ((uintptr_t)logits | (uintptr_t)ref) % 8)
+    if (!value || !shapes || !lsi || !offsets || !logits || !ref || !ws || !out) return fail(VAH_E_NULL, "%s: null pointer", fn);
+    const int64_t need = vah_msda_win_ws_bytes(S, Lq);
+    if (need < 0) return VAH_E_UNSUPPORTED;
+    if (ws_bytes < need) return fail(VAH_E_SHAPE, "%s: workspace too small (%lld < %lld)", fn, (long long)ws_bytes, (long long)need);
+    const int64_t ps = param_dtype == 1 ? 2 : 4;
+    const int64_t os = offsets_stride ? offsets_stride : kP * 2, ls = logits_stride ? logits_stride : kP;
+    if (((uintptr_t)value | (uintptr_t)out | (uintptr_t)offsets | (uintptr_t)ws) % 16 || ((uintptr_t)logits | (uintptr_t)ref) % 8 ||
+        (os * ps) % 16 || (ls * ps) % 8)
         return fail(VAH_E_ALIGN, "%s: misaligned", fn);
     hipStream_t st = (hipStream_t)stream;
-    const int64_t vs = value_dtype == 1 ? 2 : 4, ps = param_dtype == 1 ? 2 : 4;
+    const int64_t vs = value_dtype == 1 ? 2 : 4;
     LaunchScope scope("msda_fused_fwd", vs * (N * S * M * D + N * Lq * M * D) + ps * 3 * N * Lq * M * P, st,
                       4 * (N * S * M * D + 3 * N * Lq * M * P + N * Lq * M * D));
 #define VAH_CASE(VT, VC, PT, PC)                                                                                     \
     if (value_dtype == VC && param_dtype == PC)                                                                      \
-        return launch<VT, PT>(value, offsets, logits, ref, perm, group_off, group_win, (int)H, (int)W, level_start, N, S, M, Lq, \
-                              (int)ngroups, (int)max_win_px, out, st)
+        return launch<VT, PT>(value, offsets, logits, os, ls, ref, shapes, lsi, N, S, M, Lq, (int)halo, ws, out, st)
     VAH_CASE(float, 0, float, 0);
     VAH_CASE(__bf16, 1, __bf16, 1);
     VAH_CASE(__bf16, 1, float, 0);

@@ -378,6 +378,7 @@ struct FusedSrc {
     const PT *off, *logit;
     const float *ref;
     int ref_levels;
+    int os, ls;                            // elements between the offsets / logits of consecutive (n, q, m) rows
     static constexpr int kLevels = L;
     static constexpr int LP = L * kP;
     static constexpr int OW = kP * 2 * (int)sizeof(PT) / 4;      // words of one level's offsets (4 or 8)
@@ -430,14 +431,14 @@ struct FusedSrc {
     template <bool WEIGHTS>
     __device__ __forceinline__ Raw load(int row, int q, int l) const {
         Raw r;
-        const uint4 *op = reinterpret_cast<const uint4 *>(off + (row * LP + l * kP) * 2);         // 16-byte aligned
+        const uint4 *op = reinterpret_cast<const uint4 *>(off + row * os + l * kP * 2);           // 16-byte aligned
 #pragma unroll
         for (int i = 0; i < OW / 4; ++i) {
             const uint4 v = op[i];
             r.o[4 * i] = v.x, r.o[4 * i + 1] = v.y, r.o[4 * i + 2] = v.z, r.o[4 * i + 3] = v.w;
         }
         r.rp = *reinterpret_cast<const float2 *>(ref + (q * ref_levels + (ref_levels > 1 ? l : 0)) * 2);
-        const uint2 *lp = reinterpret_cast<const uint2 *>(logit + row * LP);                       // 8-byte aligned
+        const uint2 *lp = reinterpret_cast<const uint2 *>(logit + row * ls);                       // 8-byte aligned
 #pragma unroll
         for (int i = 0; i < LW / 2; ++i) {
             const uint2 v = WEIGHTS ? lp[i] : make_uint2(0, 0);
@@ -1140,8 +1141,9 @@ __global__ __launch_bounds__(64, WPS) void msda_tile(Src src, const PlanDev *__r
 // tile pass (and, for gated samples, the binning pass) left it in the records; d_offset = the records' first two
 // numbers.  One thread per row.
 template <typename PT, typename GPT, int L>
-__global__ __launch_bounds__(256) void msda_grad_finish(const PT *__restrict__ logit, const uint32_t *__restrict__ rec, int64_t rows,
-                                                        GPT *__restrict__ d_off, GPT *__restrict__ d_logit) {
+__global__ __launch_bounds__(256) void msda_grad_finish(const PT *__restrict__ logit, int64_t ls, const uint32_t *__restrict__ rec,
+                                                        int64_t rows, GPT *__restrict__ d_off, GPT *__restrict__ d_logit, int64_t dos,
+                                                        int64_t dls) {
     constexpr int LP = L * kP;
     constexpr int RW = sizeof(GPT) == 2 ? 2 : 4;
     const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1150,21 +1152,23 @@ __global__ __launch_bounds__(256) void msda_grad_finish(const PT *__restrict__ l
     float mx = -INFINITY;
 #pragma unroll
     for (int s = 0; s < LP; ++s) {
-        p[s] = (float)logit[row * LP + s];
+        p[s] = (float)logit[row * ls + s];
         mx = fmaxf(mx, p[s]);
     }
     const uint4 *rp = reinterpret_cast<const uint4 *>(rec + row * LP * RW);
     if constexpr (RW == 2) {
-        uint32_t *dp = reinterpret_cast<uint32_t *>(d_off + row * LP * 2);
+        uint32_t *dp = reinterpret_cast<uint32_t *>(d_off + row * dos);
 #pragma unroll
         for (int s = 0; s < LP; s += 4) {
             const uint4 v0 = rp[s / 2], v1 = rp[s / 2 + 1];
             g[s] = __builtin_bit_cast(float, v0.y), g[s + 1] = __builtin_bit_cast(float, v0.w);
             g[s + 2] = __builtin_bit_cast(float, v1.y), g[s + 3] = __builtin_bit_cast(float, v1.w);
-            *reinterpret_cast<uint4 *>(dp + s) = make_uint4(v0.x, v0.z, v1.x, v1.z);
+            // 8-byte stores: the rows of the module's interleaved gradient matrix are 8-byte, not 16-byte, aligned
+            *reinterpret_cast<uint2 *>(dp + s) = make_uint2(v0.x, v0.z);
+            *reinterpret_cast<uint2 *>(dp + s + 2) = make_uint2(v1.x, v1.z);
         }
     } else {
-        float *dp = reinterpret_cast<float *>(d_off + row * LP * 2);
+        float *dp = reinterpret_cast<float *>(d_off + row * dos);
 #pragma unroll
         for (int s = 0; s < LP; s += 2) {
             const uint4 v0 = rp[s], v1 = rp[s + 1];
@@ -1186,7 +1190,7 @@ __global__ __launch_bounds__(256) void msda_grad_finish(const PT *__restrict__ l
         dot += p[s] * g[s];
     }
 #pragma unroll
-    for (int s = 0; s < LP; ++s) d_logit[row * LP + s] = (GPT)(p[s] * (g[s] - dot));
+    for (int s = 0; s < LP; ++s) d_logit[row * dls + s] = (GPT)(p[s] * (g[s] - dot));
 }
 
 // ---- host side -----------------------------------------------------------------------------------
@@ -1248,11 +1252,12 @@ constexpr bool kTapsInTile = std::is_same<VT, __bf16>::value;
 
 template <typename VT, typename PT, typename GPT, int L>
 int fused_tiled(const char *fn, const Bounds &bd, const void *value, const int64_t *shapes, const int64_t *lsi, const void *off,
-                const void *logit, const float *ref, int ref_levels, int64_t N, int64_t M, int64_t Lq, int64_t S, const void *grad_out,
-                void *grad_value, int gv_bf16, void *d_off, void *d_logit, void *ws, hipStream_t st) {
+                const void *logit, int64_t os, int64_t ls, const float *ref, int ref_levels, int64_t N, int64_t M, int64_t Lq, int64_t S,
+                const void *grad_out, void *grad_value, int gv_bf16, void *d_off, void *d_logit, int64_t dos, int64_t dls, void *ws,
+                hipStream_t st) {
     constexpr bool TAPS = kTapsInTile<VT>;
     uint32_t *rec = (uint32_t *)((char *)ws + bd.off_ga);
-    FusedSrc<PT, GPT, L> src{(const PT *)off, (const PT *)logit, ref, ref_levels, rec};
+    FusedSrc<PT, GPT, L> src{(const PT *)off, (const PT *)logit, ref, ref_levels, (int)os, (int)ls, rec};
     int rc;
     if (gv_bf16) {
         if constexpr (std::is_same<VT, __bf16>::value)
@@ -1266,8 +1271,8 @@ int fused_tiled(const char *fn, const Bounds &bd, const void *value, const int64
     }
     if (rc || !TAPS) return rc;
     const int64_t rows = N * Lq * M;
-    hipLaunchKernelGGL((msda_grad_finish<PT, GPT, L>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (const PT *)logit,
-                       (const uint32_t *)rec, rows, (GPT *)d_off, (GPT *)d_logit);
+    hipLaunchKernelGGL((msda_grad_finish<PT, GPT, L>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, (const PT *)logit, ls,
+                       (const uint32_t *)rec, rows, (GPT *)d_off, (GPT *)d_logit, dos, dls);
     return check_launch(fn);
 }
 
@@ -1311,11 +1316,12 @@ int vah_msda_backward_tiled_f32(const float *value, const int64_t *shapes, const
 }
 
 int vah_msda_fused_backward_tiled(const void *value, int value_dtype, const int64_t *shapes, const int64_t *lsi,
-                                  const void *offsets, const void *logits, int param_dtype, const float *ref,
+                                  const void *offsets, const void *logits, int param_dtype, int64_t offsets_stride,
+                                  int64_t logits_stride, const float *ref,
                                   int64_t ref_levels, const void *grad_out, int64_t N, int64_t S, int64_t M, int64_t D,
                                   int64_t L, int64_t Lq, int64_t P, void *grad_value, int grad_value_dtype,
-                                  void *d_offsets, void *d_logits, int grad_param_dtype, void *ws, int64_t ws_bytes,
-                                  void *stream) {
+                                  void *d_offsets, void *d_logits, int grad_param_dtype, int64_t d_offsets_stride,
+                                  int64_t d_logits_stride, void *ws, int64_t ws_bytes, void *stream) {
     using namespace vah;
     clear_error();
     const char *fn = "vah_msda_fused_backward_tiled";
@@ -1325,31 +1331,38 @@ int vah_msda_fused_backward_tiled(const void *value, int value_dtype, const int6
     if (N * Lq * M == 0) return VAH_OK;
     if (!value || !shapes || !lsi || !offsets || !logits || !ref || !grad_out || !grad_value || !d_offsets || !d_logits || !ws)
         return fail(VAH_E_NULL, "%s: null pointer", fn);
-    if (((uintptr_t)grad_out | (uintptr_t)grad_value | (uintptr_t)ws | (uintptr_t)d_offsets) % 16 || ((uintptr_t)offsets | (uintptr_t)ref) % 8)
+    if (((uintptr_t)grad_out | (uintptr_t)grad_value | (uintptr_t)ws | (uintptr_t)offsets) % 16 || ((uintptr_t)d_offsets | (uintptr_t)ref) % 8)
         return fail(VAH_E_ALIGN, "%s: misaligned", fn);
     if ((value_dtype | param_dtype | grad_value_dtype | grad_param_dtype) & ~1)
         return fail(VAH_E_UNSUPPORTED, "%s: dtype codes must be 0 (f32) or 1 (bf16)", fn);
     if (grad_param_dtype != param_dtype && !(param_dtype == 0 && grad_param_dtype == 1))
         return fail(VAH_E_UNSUPPORTED, "%s: gradients of fp32 offsets / logits may be bf16, not the reverse", fn);
+    const int64_t vs = value_dtype ? 2 : 4, ps = param_dtype ? 2 : 4, gps = grad_param_dtype ? 2 : 4, gs = grad_value_dtype ? 2 : 4;
+    const int64_t os = offsets_stride ? offsets_stride : L * P * 2, ls = logits_stride ? logits_stride : L * P;
+    const int64_t dos = d_offsets_stride ? d_offsets_stride : L * P * 2, dls = d_logits_stride ? d_logits_stride : L * P;
+    const bool strided = os != L * P * 2 || ls != L * P || dos != L * P * 2 || dls != L * P;
+    if (os < L * P * 2 || ls < L * P || dos < L * P * 2 || dls < L * P || (os * ps) % 16 || (ls * ps) % 8 || (dos * gps) % (gps == 4 ? 16 : 8) ||
+        ((uintptr_t)logits) % 8 || (dls * gps) % gps || N * Lq * M * (os > ls ? os : ls) >= ((int64_t)1 << 31))
+        return fail(VAH_E_ALIGN, "%s: bad strides", fn);
     Bounds bd;
     if (int rc = make_bounds(fn, N, S, M, L, Lq, P, &bd)) return rc;
     if (ws_bytes < bd.total) return fail(VAH_E_SHAPE, "%s: workspace too small (%lld < %lld)", fn, (long long)ws_bytes, (long long)bd.total);
     hipStream_t st = (hipStream_t)stream;
-    const int64_t vs = value_dtype ? 2 : 4, ps = param_dtype ? 2 : 4, gps = grad_param_dtype ? 2 : 4, gs = grad_value_dtype ? 2 : 4;
     LaunchScope scope("msda_fused_bwd", vs * (N * S * M * D + N * Lq * M * D) + gs * N * S * M * D + (ps + gps) * 3 * N * Lq * M * L * P, st,
                       4 * (2 * N * S * M * D + 6 * N * Lq * M * L * P + N * Lq * M * D));
     // d(offsets), d(logits) from the gather kernel of msda_fused.hip (nothing scattered) where the tile pass does not
     // compute them itself (fp32 values)
     if (value_dtype != 1) {
-        if (grad_param_dtype != param_dtype) return fail(VAH_E_UNSUPPORTED, "%s: fp32 values write gradients in the parameter dtype", fn);
+        if (grad_param_dtype != param_dtype || strided)
+            return fail(VAH_E_UNSUPPORTED, "%s: fp32 values write gradients in the parameter dtype, contiguous tensors only", fn);
         if (int rc = msda_fused_grad_taps(value, value_dtype, shapes, lsi, offsets, logits, param_dtype, ref, ref_levels, grad_out,
                                           N, S, M, L, Lq, P, d_offsets, d_logits, st))
             return rc;
     }
 #define VAH_CASE(VT, VC, PT, PC, GPT, GC, LL)                                                                              \
     if (value_dtype == VC && param_dtype == PC && grad_param_dtype == GC && L == LL)                                      \
-        return fused_tiled<VT, PT, GPT, LL>(fn, bd, value, shapes, lsi, offsets, logits, ref, (int)ref_levels, N, M, Lq, S, \
-                                            grad_out, grad_value, grad_value_dtype, d_offsets, d_logits, ws, st)
+        return fused_tiled<VT, PT, GPT, LL>(fn, bd, value, shapes, lsi, offsets, logits, os, ls, ref, (int)ref_levels, N, M, Lq, S, \
+                                            grad_out, grad_value, grad_value_dtype, d_offsets, d_logits, dos, dls, ws, st)
 #define VAH_CASES(LL)                                  \
     VAH_CASE(float, 0, float, 0, float, 0, LL);        \
     VAH_CASE(__bf16, 1, __bf16, 1, __bf16, 1, LL);     \

@@ -20,15 +20,41 @@ from torch import nn
 
 from ..functions import MSDeformAttnFunction, MSDeformAttnFusedFunction, fused_supported
 
-try:        # fused nn.Linear (bf16 working copies, fp32 weight gradients) when the backbone package is there
-    from vitadapter.fused import linear as _linear
-    from vitadapter.fused import linear_pair as _linear_pair
-except ImportError:                                                     # ops/ used on its own
-    def _linear(lin, x):
-        return lin(x)
+# Fused nn.Linear (bf16 working copies, fp32 weight gradients) and the one-node offsets / weights pair + core when the
+# backbone package is there.  Resolved at the first forward, not at import: `vitadapter` imports this package, so an import
+# here succeeds or fails depending on which of the two is imported first.
+_FUSED = None
 
-    def _linear_pair(lin_a, lin_b, x):
-        return lin_a(x), lin_b(x)
+
+def _fused():
+    global _FUSED
+    if _FUSED is None:
+        try:
+            from vitadapter import fused as mod
+            _FUSED = mod
+        except ImportError:                                             # ops/ used on its own
+            _FUSED = False
+    return _FUSED
+
+
+def _linear(lin, x):
+    f = _fused()
+    return f.linear(lin, x) if f else lin(x)
+
+
+def _linear_pair(lin_a, lin_b, x):
+    f = _fused()
+    return f.linear_pair(lin_a, lin_b, x) if f else (lin_a(x), lin_b(x))
+
+
+def _pair_core_ok(mod, query, value, reference_points):
+    f = _fused()
+    return bool(f) and f.msda_pair_core_ok(mod, query, value, reference_points)
+
+
+def _pair_core(*args):
+    return _fused().msda_pair_core(*args)
+
 
 def _is_power_of_2(n):
     if not isinstance(n, int) or n < 0:
@@ -96,6 +122,11 @@ class MSDeformAttn(nn.Module):
             value = value.masked_fill(input_padding_mask[..., None], 0.0)
         value = value.view(N, S, M, value.shape[-1] // M)
 
+        if _pair_core_ok(self, query, value, reference_points):
+            # offsets / weights projection + softmax + locations + gather as ONE autograd node: fp32 offsets and logits
+            # straight from the GEMM accumulators, read in place by the kernels (vitadapter/fused.py::_MSDAPairCore)
+            out = _pair_core(self, query, value, input_spatial_shapes, input_level_start_index, reference_points)
+            return _linear(self.output_proj, out)
         offsets, logits = _linear_pair(self.sampling_offsets, self.attention_weights, query)
         offsets, logits = offsets.view(N, Lq, M, L, P, 2), logits.view(N, Lq, M, L * P)
         if fused_supported(value, offsets, logits, reference_points, L, P):

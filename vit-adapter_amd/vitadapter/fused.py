@@ -12,7 +12,7 @@ import torch.nn.functional as F
 
 import _vah
 
-ENABLED = {'layer_norm': True, 'residual': True, 'residual_ln': True, 'dwconv': True, 'linear': True, 'bn_tail': True,
+ENABLED = {'pair_core': True, 'layer_norm': True, 'residual': True, 'residual_ln': True, 'dwconv': True, 'linear': True, 'bn_tail': True,
            'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True, 'maps_in': True, 'linear_pair': True, 'maxpool': True, 'conv1x1': True, 'ln_dual': True, 'wgrad_fin': True, 'spm_nhwc': True, 'up_gemm': True, 'patch_gemm': True, 'wgrad_overlap': True}
 for _k in os.environ.get('VAH_FUSED_DISABLE', '').split(','):      # e.g. VAH_FUSED_DISABLE=residual_ln,bn_tail (A/B runs)
     if _k:
@@ -343,70 +343,60 @@ class _SideStream:
       fork:  side.wait_stream(current)                       - the operands exist
       join:  current.wait_stream(side), ONCE per backward pass, from an autograd engine callback queued by the first
              fork of the pass (the engine runs callbacks after the last node: before anything can read a .grad)
+    A gradient left on the side stream is NOT handed to autograd: the engine may add it to another gradient of the
+    same parameter (a second use of the weight by any operator, two forwards before one backward, retain_graph) on the
+    main stream the moment the node returns, which would race with the side stream.  The node returns None for it and
+    the join, once the main stream is ordered behind the side stream, stores it in (or adds it to) the parameter's
+    .grad itself - what AccumulateGrad does, at the end of the pass instead of in the middle.  That is only the same thing
+    when nothing observes the accumulation: see may_defer.
     The operands are kept alive until the join (their memory is freed on the main stream's pool only after the main
     stream is ordered behind the side stream), the gradients are allocated while the side stream is current.
-    Off when a process group with more than one rank exists (DDP's bucket hooks read a gradient the moment autograd
+    Off when a process group with more than one rank exists (bucket hooks read a gradient the moment autograd
     produces it) and under HIP-graph capture (the fork / join edges cost a replayed graph more than the overlap gains).
     Measured on base_det, eager: 27.5 -> 26.7 ms per step."""
 
     def __init__(self):
         self.streams = {}
-        self.pending = {}          # device index -> (main stream, [tensors kept alive])
-        self.deferred = {}         # id(parameter) -> gradients that reached the parameter since its gradient was deferred (this pass)
-        self.hooked = {}           # id(parameter) -> weakref (the parameters that carry the ordering hook)
+        self.pending = {}          # device index -> (main stream, [tensors kept alive], [(parameter, gradient)])
 
     def begin_epoch(self):
         for idx in list(self.pending):      # a backward pass that died before its callback: join now, never leave a fork open
             self.join(idx)
-        self.deferred.clear()
 
     def note(self, weight, bias):
         """Forward: weak references to the parameters whose gradients the backward may leave on the side stream.  The
-        DECISION is taken at backward time (may_defer): a decision taken in the forward does not survive two forwards
-        before one backward, a second backward with retain_graph, or a second use of the weight by another operator."""
+        DECISION is taken at backward time (may_defer)."""
         import weakref
         if not weight.is_leaf or (bias is not None and not bias.is_leaf) or not (BF16_COPIES.epoch & 1):
             return None
-        return (weakref.ref(weight), weakref.ref(bias) if bias is not None else None)
-
-    def _order_hook(self, pid):
-        def hook(grad):
-            n = self.deferred.get(pid)
-            if n is not None:
-                self.deferred[pid] = n + 1
-                # n == 0: the deferred gradient itself arrives - autograd only stores it.  Any further gradient for this
-                # parameter in the same pass (a second forward of the module, another operator using the weight) is ADDED
-                # to the stored one on the current stream: that add has to come behind the side stream's writes
-                if n >= 1 and grad.is_cuda:
-                    idx = grad.device.index if grad.device.index is not None else torch.cuda.current_device()
-                    side = self.streams.get(idx)
-                    if side is not None:
-                        torch.cuda.current_stream(grad.device).wait_stream(side)
+        if not weight.requires_grad or (bias is not None and not bias.requires_grad):
             return None
-        return hook
+        return tuple(weakref.ref(p) for p in (weight, bias) if p is not None)
+
+    @staticmethod
+    def _only_accumulated(p):
+        """Will this backward pass do nothing with the parameter's gradient but accumulate it into .grad?  No tensor hooks
+        (they see or rewrite the gradient in mid-pass), and AccumulateGrad scheduled by the engine: under
+        torch.autograd.grad() gradients are RETURNED, and backward(inputs=...) may leave the parameter out."""
+        if p is None or getattr(p, '_backward_hooks', None) or getattr(p, '_post_accumulate_grad_hooks', None):
+            return False
+        with torch.enable_grad():       # the parameter's AccumulateGrad node (not kept: a node that outlives its pass pins a stream)
+            acc = p.view_as(p).grad_fn.next_functions[0][0]
+        try:
+            return bool(torch._C._will_engine_execute_node(acc))
+        except RuntimeError:            # autograd.grad(), or not inside a backward pass at all
+            return False
 
     def may_defer(self, token, dev):
-        """Backward: may this node's weight / bias gradients be produced on the side stream?  Only if autograd will
-        merely STORE them: every parameter alive, without a .grad (no accumulation across micro-batches or backward
-        passes) and without a gradient already deferred in this pass."""
+        """Backward: may this node's weight / bias gradients be produced on the side stream and stored by the join?"""
         if token is None or not (ENABLED['wgrad_overlap'] and dev.type == 'cuda'):
-            return False
-        params = [r() for r in token if r is not None]
-        if any(p is None or p.grad is not None or id(p) in self.deferred for p in params):
             return False
         if torch.cuda.is_current_stream_capturing():
             return False               # measured: ~80 fork / join edges per step cost a replayed HIP graph 0.35 ms more than the overlap gains
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             return False
-        import weakref
-        for p in params:
-            self.deferred[id(p)] = 0
-            ref = self.hooked.get(id(p))
-            if ref is None or ref() is not p:               # once per parameter: orders later gradients behind the side stream
-                p.register_hook(self._order_hook(id(p)))
-                self.hooked[id(p)] = weakref.ref(p)
-        return True
+        return all(self._only_accumulated(r()) for r in token)
 
     def fork(self, dev, keep):
         """-> the side stream, ordered behind everything enqueued on the current stream so far."""
@@ -418,18 +408,33 @@ class _SideStream:
         side.wait_stream(cur)
         entry = self.pending.get(idx)
         if entry is None:
-            self.pending[idx] = entry = (cur, [])
+            self.pending[idx] = entry = (cur, [], [])
             torch.autograd.Variable._execution_engine.queue_callback(lambda: self.join(idx))
         entry[1].extend(keep)
         return side
 
+    def deliver(self, dev, token, grads):
+        """The side stream's gradients of this node, for the join to accumulate (same order as the token)."""
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        self.pending[idx][2].extend((r(), g) for r, g in zip(token, grads))
+
     def join(self, idx):
         entry = self.pending.pop(idx, None)
-        if entry is not None:
-            entry[0].wait_stream(self.streams[idx])
-            entry[1].clear()
-        if not self.pending:
-            self.deferred.clear()
+        if entry is None:
+            return
+        main, keep, grads = entry
+        main.wait_stream(self.streams[idx])
+        with torch.no_grad(), torch.cuda.stream(main):
+            for p, g in grads:
+                if p is None:           # the parameter died with its module before the pass ended
+                    continue
+                if g.dtype != p.dtype:
+                    g = g.to(p.dtype)
+                if p.grad is None:
+                    p.grad = g.view_as(p)
+                else:
+                    p.grad.add_(g.view_as(p))
+        keep.clear()
 
 
 SIDE = _SideStream()
@@ -470,7 +475,7 @@ class _LinearBF16(torch.autograd.Function):
         deferred = fin and SIDE.may_defer(ctx.side, g2.device)
         if deferred:                    # weight / bias gradients beside the input gradient, on the side stream
             with torch.cuda.stream(SIDE.fork(g2.device, (g2, x2))):
-                gw, gb = _wgrad_bgrad(g2, x2)
+                SIDE.deliver(g2.device, ctx.side, _wgrad_bgrad(g2, x2))
         if ctx.needs_input_grad[0]:
             gx = gemm_bf16(g2, wb).view(ctx.in_shape)
             if gx.dtype != ctx.in_dtype:
@@ -583,6 +588,129 @@ def linear_pair(lin_a, lin_b, x):
             and type(lin_a) is torch.nn.Linear and type(lin_b) is torch.nn.Linear):
         return _LinearPairBF16.apply(x, wa, lin_a.bias, wb, lin_b.bias, PAIR_COPIES.get(lin_a, lin_b))
     return linear(lin_a, x), linear(lin_b, x)
+
+
+class _PairCoreCopies:
+    """bf16 rows of [sampling_offsets; attention_weights] reordered head by head - [offsets of head 0 | logits of head 0 |
+    offsets of head 1 | ...] - with the fp32 bias in the same order, and the permutation (see msda_pair_core)."""
+
+    def __init__(self):
+        self.entries = {}
+
+    def get(self, a, b, M):
+        key = (id(a.weight), id(b.weight))
+        epoch = BF16_COPIES.epoch
+        e = self.entries.get(key)
+        if e is not None and e[0] == epoch and (epoch & 1) and e[1].device == a.weight.device and e[4]() is a.weight:
+            return e[1], e[2], e[3]
+        import weakref
+        na, nb = a.weight.shape[0], b.weight.shape[0]
+        po, pl = na // M, nb // M
+        dev = a.weight.device
+        perm = e[3] if (e is not None and e[3].device == dev) else torch.cat(
+            [torch.cat((torch.arange(m * po, (m + 1) * po), na + torch.arange(m * pl, (m + 1) * pl))) for m in range(M)]).to(dev)
+        with torch.no_grad():
+            w = torch.cat([a.weight.detach(), b.weight.detach()], 0).index_select(0, perm).to(torch.bfloat16)
+            bias = torch.cat([a.bias.detach(), b.bias.detach()], 0).float().index_select(0, perm)
+        if len(self.entries) > 1024:
+            self.entries.clear()
+        self.entries[key] = (epoch, w, bias, perm, weakref.ref(a.weight))
+        return w, bias, perm
+
+
+PAIR_CORE_COPIES = _PairCoreCopies()
+
+
+class _MSDAPairCore(torch.autograd.Function):
+    """MSDeformAttn's sampling_offsets / attention_weights Linear pair AND the fused deformable-attention core as one
+    autograd node (ref ops/modules/ms_deform_attn.py:108-128): ONE GEMM over the two weight matrices with its output
+    rows ordered head by head - (n, q, m) row = [L*P*2 offsets | L*P logits], fp32 straight from the accumulators - which
+    the MSDA kernels read in place through a row stride.  What this removes per call: the two slice copies of the
+    paired GEMM's output and the two that rebuild the gradient matrix, the bf16 rounding of the sampling offsets (the
+    reference keeps them in fp32: ms_deform_attn_func.py:21; d(out)/d(location) jumps at integer pixel coordinates, so
+    8-bit offsets cost the upstream gradients 0.2-0.35 of relative L2 on small problems), and one cache line per list
+    entry in the backward's tile pass (a row's offsets and logits now sit side by side).  The gradients come back in
+    bf16, written by the tile pass into the gradient matrix of the pair GEMM's backward in the same row order."""
+
+    @staticmethod
+    def forward(ctx, query, value, shapes, lsi, ref, wa, ba, wb, bb, copies, M, L, P):
+        from ops.functions import ms_deform_attn_fused as mf
+        K = query.shape[-1]
+        x2 = query.reshape(-1, K)
+        if x2.dtype != torch.bfloat16:
+            x2 = x2.to(torch.bfloat16)
+        x2 = x2.contiguous()
+        w, bias, perm = copies
+        y = gemm_bf16(x2, w, trans_b=True, bias=bias, out_dtype=torch.float32)         # (N * Lq, M * 3 * L * P) fp32
+        N, Lq = query.shape[0], query.shape[1]
+        PS = 3 * L * P
+        yv = y.view(N, Lq, M, PS)
+        offsets = yv[..., :2 * L * P].unflatten(-1, (L, P, 2))
+        logits = yv[..., 2 * L * P:]
+        value = value.contiguous()
+        refc = ref.detach().float().contiguous().view(Lq, -1, 2)
+        out = mf.fused_forward(value, shapes, lsi, offsets, logits, PS, PS, refc)
+        ctx.save_for_backward(x2, w, y, value, shapes, lsi, refc, perm)
+        ctx.dims = (N, Lq, M, L, P, wa.shape[0])
+        ctx.in_shape, ctx.in_dtype = query.shape, query.dtype
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        x2, w, y, value, shapes, lsi, refc, perm = ctx.saved_tensors
+        N, Lq, M, L, P, na = ctx.dims
+        S, D = value.shape[1], value.shape[3]
+        PS = 3 * L * P
+        R = x2.shape[0]
+        gout = gout.contiguous().to(value.dtype)
+        g = torch.empty((R, M * PS), dtype=torch.bfloat16, device=x2.device)
+        grad_value = torch.empty_like(value)
+        ws_bytes = _vah.lib.vah_msda_tile_ws_bytes(N, S, M, L, Lq, P)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
+        with _vah.on(value.device):
+            rc = _vah.lib.vah_msda_fused_backward_tiled(
+                value.data_ptr(), 1, shapes.data_ptr(), lsi.data_ptr(), y.data_ptr(), y.data_ptr() + 2 * L * P * 4, 0, PS, PS,
+                refc.data_ptr(), refc.shape[1], gout.data_ptr(), N, S, M, D, L, Lq, P, grad_value.data_ptr(), 1,
+                g.data_ptr(), g.data_ptr() + 2 * L * P * 2, 1, PS, PS, ws.data_ptr(), ws_bytes, _stream(value))
+        _vah.check(rc, 'vah_msda_fused_backward_tiled')
+        gx = gw = gbias = None
+        if ctx.needs_input_grad[0]:
+            gx = gemm_bf16(g, w).view(ctx.in_shape)
+            if gx.dtype != ctx.in_dtype:
+                gx = gx.to(ctx.in_dtype)
+        if any(ctx.needs_input_grad[5:9]):
+            gwp, gbp = _wgrad_bgrad(g, x2)
+            inv = torch.empty_like(perm)
+            inv[perm] = torch.arange(perm.numel(), device=perm.device)
+            gw, gbias = gwp.index_select(0, inv), gbp.index_select(0, inv)
+        return (gx, grad_value if ctx.needs_input_grad[1] else None, None, None, None,
+                gw[:na] if gw is not None else None, gbias[:na] if gbias is not None else None,
+                gw[na:] if gw is not None else None, gbias[na:] if gbias is not None else None, None, None, None, None)
+
+
+def msda_pair_core_ok(mod, query, value, reference_points):
+    """The one-node form of MSDeformAttn's offsets / weights pair + core: bf16 autocast on the GPU with bf16 values, the
+    tile-pass backward and shapes the fused kernels cover (D == 32, P == 4, L in {1, 3, 4}), reference points shared by
+    the batch."""
+    import os
+    a, b = mod.sampling_offsets, mod.attention_weights
+    M, L, P = mod.n_heads, mod.n_levels, mod.n_points
+    return (ENABLED['linear'] and ENABLED['linear_pair'] and ENABLED['pair_core'] and query.is_cuda and _bf16_autocast()
+            and value.dtype == torch.bfloat16 and value.dim() == 4 and value.shape[-1] == 32 and P == 4 and L in (1, 3, 4)
+            and (M * 3 * L * P) % 8 == 0            # rows of the pair GEMM / its column sums: 16-byte multiples
+            and type(a) is torch.nn.Linear and type(b) is torch.nn.Linear and a.bias is not None and b.bias is not None
+            and a.weight.dtype == torch.float32 and b.weight.dtype == torch.float32 and a.weight.shape[1] % 8 == 0
+            and reference_points.shape[0] == 1 and reference_points.shape[-1] == 2 and reference_points.shape[2] in (1, L)
+            and query.numel() > 0 and value.numel() > 0 and query.dtype in (torch.bfloat16, torch.float32)
+            and os.environ.get('VAH_MSDA_FUSED', '1') != '0' and os.environ.get('VAH_MSDA_TILED', '1') != '0'
+            and _vah.lib.vah_msda_tile_ws_bytes(value.shape[0], value.shape[1], M, L, query.shape[1], P) >= 0)
+
+
+def msda_pair_core(mod, query, value, shapes, lsi, reference_points):
+    a, b = mod.sampling_offsets, mod.attention_weights
+    return _MSDAPairCore.apply(query, value, shapes, lsi, reference_points, a.weight, a.bias, b.weight, b.bias,
+                               PAIR_CORE_COPIES.get(a, b, mod.n_heads), mod.n_heads, mod.n_levels, mod.n_points)
 
 
 class _Conv1x1BF16(torch.autograd.Function):
