@@ -151,14 +151,14 @@ def msda_source_digest():
 
 def pmc_traffic(kernel, args, preset_kw):
     """HBM bytes per launch of the dominant MSDA entry point from the committed PMC pass
-    (profiles/r02_msda_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
+    (profiles/r03_msda_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of
     tools/prof_msda_single.py, gfx950 FETCH_SIZE x2 correction, written by tools/pmc_msda_summary.py
     together with the digest of the kernel sources it measured).  Only for the exact shapes that
     pass measured (BASELINE configs[2]: 4 injector + 6 extractor calls per direction and step) and
     only while the kernel sources are the ones it measured; None (-> "traffic": null) otherwise."""
     if args.preset != 'base_det' or list(args.size) != [1024, 1024] or args.batch != 2:
         return None
-    path = os.path.join(ROOT, 'profiles', 'r02_msda_pmc.json')
+    path = os.path.join(ROOT, 'profiles', 'r03_msda_pmc.json')
     try:
         pmc = json.load(open(path))
         if pmc.get('msda_source_digest') != msda_source_digest():

@@ -132,6 +132,10 @@ int vah_msda_fused_backward(const void *value, int value_dtype, const int64_t *s
  * and the device copies of spatial_shapes / level_start_index: no host copy of the geometry, nothing cached by tensor
  * identity, capturable in a HIP graph with fresh shape tensors.
  *   ws / ws_bytes : device workspace of at least vah_msda_win_ws_bytes(S, Lq) bytes, 16-byte aligned
+ *   ws_holds_schedule : 0 = build the schedule into ws first (one single-workgroup kernel, ~20 us for 21 504 queries);
+ *                   1 = ws still holds the schedule an earlier call built from the SAME ref, spatial_shapes,
+ *                   level_start_index, S and Lq (the adapter makes six extractor calls per forward with one set of
+ *                   deform inputs): only the forward kernel runs.  The forward kernel does not write to ws.
  * A workgroup walks (n, group, head) items: it stages the window once, then one lane per query evaluates its four
  * samples against it (replaces ms_deform_im2col_cuda.cuh:237-299 + the module's softmax / location lines).
  * ------------------------------------------------------------------------------------ */
@@ -140,7 +144,7 @@ int vah_msda_fused_forward_win(const void *value, int value_dtype, const int64_t
                                const void *offsets, const void *logits, int param_dtype,
                                int64_t offsets_stride, int64_t logits_stride, const float *ref,
                                int64_t N, int64_t S, int64_t M, int64_t D, int64_t Lq, int64_t P,
-                               int64_t halo, void *ws, int64_t ws_bytes, void *out, void *stream);
+                               int64_t halo, void *ws, int64_t ws_bytes, int ws_holds_schedule, void *out, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * TILED BACKWARD: grad_value without atomics and without a zero-fill, for ANY sampling locations

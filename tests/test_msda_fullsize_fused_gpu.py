@@ -183,3 +183,54 @@ def test_fused_core_is_capturable_with_fresh_geometry_tensors(L, shapes, qshapes
     for g, w, nm in zip(got, want, ('out', 'grad_value', 'd_offsets', 'd_logits')):
         # list order inside a tile depends on atomics: sums may differ in the last bits between two runs
         assert (g.float() - w).abs().max().item() <= 2e-2 * max(1.0, w.abs().max().item()), nm
+
+
+def test_window_schedule_rides_on_the_reference_points_tensor():
+    """ops/functions/ms_deform_attn_fused.py::_window_workspace: the extractor's six calls of one forward share the window
+    schedule through an attribute on the reference_points tensor object.  Reused only for the same objects, unmodified, in
+    the same pass; the result never depends on it (the schedule only decides which corner rows come from LDS)."""
+    from ops.functions import ms_deform_attn_fused as mf
+    torch.manual_seed(5)
+    N, M, D, P, L = 2, 6, 32, 4, 1
+    shapes, qshapes = [(16, 24)], [(32, 48), (16, 24), (8, 12)]
+    S, Lq = 16 * 24, sum(h * w for h, w in qshapes)
+    value = torch.randn(N, S, M, D, device='cuda').bfloat16()
+    hw = torch.as_tensor(shapes, dtype=torch.long, device='cuda')
+    lsi = cases.level_start_index(shapes).cuda()
+    ref = cases.reference_grid(qshapes).cuda()                      # (1, Lq, 1, 2): the tensor the module is called with
+
+    def rows():
+        y = torch.randn(N, Lq, M, 12, device='cuda') * 2
+        return y[..., :8].unflatten(-1, (L, P, 2)), y[..., 8:]
+
+    def call(offs, logs, carrier, token):
+        return mf.fused_forward(value, hw, lsi, offs, logs, 12, 12, ref.float().contiguous().view(Lq, -1, 2), carrier=carrier, token=token)
+
+    o1, l1 = rows()
+    want1 = call(o1, l1, None, None)
+    assert not hasattr(ref, '_vah_win_schedule')
+    got1 = call(o1, l1, ref, 7)
+    ws1 = ref._vah_win_schedule.ws
+    assert torch.equal(got1, want1)
+    o2, l2 = rows()
+    got2 = call(o2, l2, ref, 7)                                      # same objects, same pass: only the forward kernel runs
+    assert ref._vah_win_schedule.ws is ws1
+    assert torch.equal(got2, call(o2, l2, None, None))
+    got3 = call(o2, l2, ref, 9)                                      # another pass
+    ws3 = ref._vah_win_schedule.ws
+    assert ws3 is not ws1 and torch.equal(got3, got2)
+    ref.copy_(ref.flip(1))                                           # written in place: the version counter moves
+    want4 = call(o2, l2, None, None)
+    got4 = call(o2, l2, ref, 9)
+    assert ref._vah_win_schedule.ws is not ws3 and torch.equal(got4, want4)
+    ws4 = ref._vah_win_schedule.ws
+    hw2 = hw.clone()                                                 # a fresh geometry tensor
+    got5 = mf.fused_forward(value, hw2, lsi, o2, l2, 12, 12, ref.float().contiguous().view(Lq, -1, 2), carrier=ref, token=9)
+    assert ref._vah_win_schedule.ws is not ws4 and torch.equal(got5, want4)
+    side = torch.cuda.Stream()                                       # another stream
+    side.wait_stream(torch.cuda.current_stream())
+    ws5 = ref._vah_win_schedule.ws
+    with torch.cuda.stream(side):
+        got6 = mf.fused_forward(value, hw2, lsi, o2, l2, 12, 12, ref.float().contiguous().view(Lq, -1, 2), carrier=ref, token=9)
+    torch.cuda.current_stream().wait_stream(side)
+    assert ref._vah_win_schedule.ws is not ws5 and torch.equal(got6, want4)

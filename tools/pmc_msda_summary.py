@@ -1,13 +1,13 @@
 #!/usr/bin/env python
-"""Summarise rocprofv3 --pmc passes of tools/prof_msda_single.py into profiles/r02_msda_pmc.json.
+"""Summarise rocprofv3 --pmc passes of tools/prof_msda_single.py into profiles/r03_msda_pmc.json.
 
 Layout expected (one directory per pass, csv output):
     <root>/<cfg>_n<noise>_<COUNTER>/**/*counter_collection.csv      COUNTER in FETCH_SIZE, WRITE_SIZE
-    python tools/pmc_msda_summary.py <root> <iters> > profiles/r02_msda_pmc.json
+    python tools/pmc_msda_summary.py <root> <iters> > profiles/r03_msda_pmc.json
 Counter unit KiB.  hbm_bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024 (gfx950: FETCH_SIZE reports half of
 the bytes of wide coalesced reads, MI355X_MICROARCH.md "HBM"); per call = sum over the kernels of one
-forward (msda_fused_fwd) / backward (msda_bin + msda_tile_gv + msda_logit_grad, or msda_fused_bwd_vec4 in front
-where the tile pass leaves d(offsets) to it) call.  The JSON is stamped with the digest of the MSDA kernel
+forward (msda_win_schedule + msda_fused_fwd_win, or msda_fused_fwd) / backward (msda_plan + msda_bin + msda_tile +
+msda_grad_finish) call.  The JSON is stamped with the digest of the MSDA kernel
 sources (bench.py::msda_source_digest): bench.py reports it as roofline.traffic only while they are unchanged.
 """
 import csv
@@ -32,13 +32,13 @@ def main():
             if r['Counter_Name'] != counter:
                 continue
             n = r['Kernel_Name']
-            if 'msda_fused_fwd' in n:
+            if 'msda_fused_fwd' in n or 'msda_win_schedule' in n:
                 acc[(key, 'fwd')][counter] += float(r['Counter_Value']) / iters
-            elif any(t in n for t in ('msda_fused_bwd', 'msda_tile_gv', 'msda_bin', 'msda_logit_grad')):
+            elif any(t in n for t in ('msda_fused_bwd', 'msda_tile', 'msda_bin', 'msda_plan', 'msda_grad_finish')):
                 acc[(key, 'bwd')][counter] += float(r['Counter_Value']) / iters
     out = {'_note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace only) of '
-                    'tools/prof_msda_single.py <cfg> %d <noise> (fused MSDA core, bf16 IO), MI355X, round-2 kernels (tile-pass '
-                    'backward).  n0 = offsets of a freshly initialised model (what bench.py runs), '
+                    'tools/prof_msda_single.py <cfg> %d <noise> pair (fused MSDA core as the module calls it: bf16 value / out, fp32 [offsets | logits] rows, '
+                    'bf16 gradient rows), MI355X, round-3 kernels (device-planned persistent tile pass).  n0 = offsets of a freshly initialised model (what bench.py runs), '
                     'n1 = ring bias + N(0,1) px ("adapter" offsets).  '
                     'Counter unit KiB; per call = sum over the kernels of one forward / backward call. '
                     'hbm_bytes = 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (gfx950 correction of MI355X_MICROARCH.md).' % iters}

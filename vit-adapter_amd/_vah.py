@@ -72,7 +72,7 @@ lib.vah_msda_fused_forward.argtypes = [_p, _ci, _p, _p, _p, _p, _ci, _i64, _i64,
 lib.vah_msda_fused_forward.restype = ctypes.c_int
 lib.vah_msda_fused_backward.argtypes = [_p, _ci, _p, _p, _p, _p, _ci, _p, _i64, _p] + [_i64] * 7 + [_p] * 4
 lib.vah_msda_fused_backward.restype = ctypes.c_int
-lib.vah_msda_fused_forward_win.argtypes = [_p, _ci, _p, _p, _p, _p, _ci, _i64, _i64, _p] + [_i64] * 7 + [_p, _i64, _p, _p]
+lib.vah_msda_fused_forward_win.argtypes = [_p, _ci, _p, _p, _p, _p, _ci, _i64, _i64, _p] + [_i64] * 7 + [_p, _i64, _ci, _p, _p]
 lib.vah_msda_win_ws_bytes.argtypes = [_i64, _i64]
 lib.vah_msda_win_ws_bytes.restype = _i64
 lib.vah_msda_fused_forward_win.restype = ctypes.c_int

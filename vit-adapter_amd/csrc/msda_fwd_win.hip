@@ -69,18 +69,37 @@ static_assert(sizeof(WinHeader) == 64, "header");
 constexpr int kTile = 8;
 constexpr int kSchedThreads = 1024;
 constexpr int kLdsGroups = 4096;
+constexpr int kRegQ = 32;             // queries a schedule thread keeps in registers (fast path: Lq <= 32 768)
 
-__device__ __forceinline__ int group_of(float rx, float ry, int H, int W, int ntx, int nty) {
-    const int ty = min(max((int)floorf(ry * (float)H / (float)kTile), 0), nty - 1);
-    const int tx = min(max((int)floorf(rx * (float)W / (float)kTile), 0), ntx - 1);
+// Group of a reference point: the 8 x 8-pixel tile of the value map it falls in.  Only a heuristic (a corner outside the
+// staged window is read from global memory: same result), so one multiply per coordinate - sx = W / 8, sy = H / 8 - and
+// no division: the schedule kernel is ONE workgroup and its instruction count is its run time.
+__device__ __forceinline__ int group_of(float rx, float ry, float sx, float sy, int ntx, int nty) {
+    const int ty = min(max((int)(ry * sy), 0), nty - 1);
+    const int tx = min(max((int)(rx * sx), 0), ntx - 1);
     return ty * ntx + tx;
 }
 
 __global__ __launch_bounds__(kSchedThreads) void msda_win_schedule(const float *__restrict__ ref, const int64_t *__restrict__ shapes,
                                                                    const int64_t *__restrict__ lsi, int Lq, int64_t S, int Gmax,
                                                                    unsigned char *__restrict__ ws) {
-    __shared__ int s_cnt[kLdsGroups];
-    __shared__ int s_scan[kSchedThreads];
+    extern __shared__ int s_dyn[];
+    int *s_cnt = s_dyn, *s_scan = s_dyn + kLdsGroups;
+    unsigned short *s_g = reinterpret_cast<unsigned short *>(s_scan + kSchedThreads);       // group of query q (fast path)
+    // Fast path (the adapter: 21 504 queries, 64 groups; Lq <= 32 768, <= 4096 groups).  This kernel is ONE workgroup:
+    // every dependent trip to memory and every serialised LDS atomic shows in full (one dependent load per query and
+    // pass, one returning atomic per query: 24 us, more than half of the forward itself).  So: the reference points
+    // are read once, coalesced, all loads of a thread in flight together and before the level geometry is read; the
+    // group of every query goes to LDS; then a thread takes K CONSECUTIVE queries - consecutive queries of a grid row
+    // fall into the same group in runs (16 of a 128-wide grid on a 64-wide map), it sees 2 - 3 runs - and does ONE
+    // counting atomic per run (the run's first query adds the run's length; the value returned is its first rank).
+    const bool fits = Lq <= kRegQ * kSchedThreads;
+    float2 rp[kRegQ];
+    if (fits) {
+#pragma unroll
+        for (int i = 0; i < kRegQ; ++i)        // clamped: the loads are unconditional
+            rp[i] = *reinterpret_cast<const float2 *>(ref + (int64_t)min(i * kSchedThreads + (int)threadIdx.x, Lq - 1) * 2);
+    }
     const Level lv = read_level(shapes, lsi, 0, S);
     WinHeader *hd = reinterpret_cast<WinHeader *>(ws);
     int *group_off = reinterpret_cast<int *>(ws + sizeof(WinHeader));
@@ -95,40 +114,105 @@ __global__ __launch_bounds__(kSchedThreads) void msda_win_schedule(const float *
         *hd = h;
     }
     if (!ok) return;
+    const float sx = (float)lv.W * (1.f / kTile), sy = (float)lv.H * (1.f / kTile);
     const bool lds = G <= kLdsGroups;
     int *cnt = lds ? s_cnt : cursor;
     for (int i = threadIdx.x; i < G; i += kSchedThreads) cnt[i] = 0;
     __syncthreads();
-    for (int q = threadIdx.x; q < Lq; q += kSchedThreads) {
-        const float2 rp = *reinterpret_cast<const float2 *>(ref + (int64_t)q * 2);
-        atomicAdd(&cnt[group_of(rp.x, rp.y, lv.H, lv.W, ntx, nty)], 1);
-    }
-    __syncthreads();
-    // exclusive scan of the G counts: each thread takes a contiguous slice
-    const int per = (G + kSchedThreads - 1) / kSchedThreads;
-    const int b0 = min((int)threadIdx.x * per, G), b1 = min(b0 + per, G);
-    int sum = 0;
-    for (int i = b0; i < b1; ++i) sum += cnt[i];
-    s_scan[threadIdx.x] = sum;
-    __syncthreads();
-    for (int d = 1; d < kSchedThreads; d <<= 1) {
-        const int v = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0;
+    const bool regs = lds && fits;
+    uint32_t gr[kRegQ];
+    const int K = (Lq + kSchedThreads - 1) / kSchedThreads, q0 = (int)threadIdx.x * K;     // phase 2: queries [q0, q0 + K) of this thread
+    if (regs) {
+        // (K is uniform: the guards below are scalar branches, iterations beyond K cost nothing)
+#pragma unroll
+        for (int i = 0; i < kRegQ; ++i) {
+            const int q = i * kSchedThreads + (int)threadIdx.x;
+            if (i < K && q < Lq) s_g[q] = (unsigned short)group_of(rp[i].x, rp[i].y, sx, sy, ntx, nty);
+        }
         __syncthreads();
-        s_scan[threadIdx.x] += v;
-        __syncthreads();
+        int gq[kRegQ];
+#pragma unroll
+        for (int i = 0; i < kRegQ; ++i) gq[i] = (i < K && q0 + i < Lq) ? (int)s_g[q0 + i] : -1;
+        int len[kRegQ];                         // queries from i to the end of its run
+        len[kRegQ - 1] = 1;
+#pragma unroll
+        for (int i = kRegQ - 2; i >= 0; --i) len[i] = (i < K && gq[i + 1] == gq[i]) ? len[i + 1] + 1 : 1;
+        int base[kRegQ];
+#pragma unroll
+        for (int i = 0; i < kRegQ; ++i) {       // independent atomics: several in flight
+            base[i] = -1;
+            if (i < K) {
+                const bool head = gq[i] >= 0 && (i == 0 || gq[i - 1] != gq[i]);
+                if (head) base[i] = atomicAdd(&s_cnt[gq[i]], len[i]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kRegQ; ++i) {
+            gr[i] = 0u;
+            if (i < K) {
+                if (i > 0 && base[i] < 0) base[i] = base[i - 1] + 1;          // behind the head: the next rank
+                gr[i] = gq[i] >= 0 ? (uint32_t)gq[i] | ((uint32_t)base[i] << 12) : 0u;     // rank < Lq <= 2^15, group < 2^12
+            }
+        }
+    } else {
+        for (int q = threadIdx.x; q < Lq; q += kSchedThreads) {
+            const float2 r1 = *reinterpret_cast<const float2 *>(ref + (int64_t)q * 2);
+            atomicAdd(&cnt[group_of(r1.x, r1.y, sx, sy, ntx, nty)], 1);
+        }
     }
-    int run = s_scan[threadIdx.x] - sum;
-    for (int i = b0; i < b1; ++i) {
-        const int c = cnt[i];
-        group_off[i] = run;
-        cnt[i] = run;                       // becomes the group's write cursor
-        run += c;
-    }
-    if (threadIdx.x == kSchedThreads - 1) group_off[G] = s_scan[kSchedThreads - 1];
     __syncthreads();
-    for (int q = threadIdx.x; q < Lq; q += kSchedThreads) {
-        const float2 rp = *reinterpret_cast<const float2 *>(ref + (int64_t)q * 2);
-        perm[atomicAdd(&cnt[group_of(rp.x, rp.y, lv.H, lv.W, ntx, nty)], 1)] = q;
+    // exclusive scan of the G counts
+    if (G <= 64) {                       // the adapter: one wave, shuffles
+        if (threadIdx.x < 64) {
+            const int lane = (int)threadIdx.x;
+            const int c = lane < G ? cnt[lane] : 0;
+            int incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const int v = __shfl_up(incl, d);
+                if (lane >= d) incl += v;
+            }
+            if (lane < G) {
+                group_off[lane] = incl - c;
+                cnt[lane] = incl - c;        // the group's first slot
+            }
+            if (lane == 0) group_off[G] = Lq;          // every query is in exactly one group
+        }
+    } else {                             // each thread takes a contiguous slice
+        const int per = (G + kSchedThreads - 1) / kSchedThreads;
+        const int b0 = min((int)threadIdx.x * per, G), b1 = min(b0 + per, G);
+        int sum = 0;
+        for (int i = b0; i < b1; ++i) sum += cnt[i];
+        s_scan[threadIdx.x] = sum;
+        __syncthreads();
+        const int nact = min(kSchedThreads, G);              // slices beyond the groups are empty: they add nothing
+        for (int d = 1; d < nact; d <<= 1) {
+            const int v = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0;
+            __syncthreads();
+            s_scan[threadIdx.x] += v;
+            __syncthreads();
+        }
+        int run = s_scan[threadIdx.x] - sum;
+        for (int i = b0; i < b1; ++i) {
+            const int c = cnt[i];
+            group_off[i] = run;
+            cnt[i] = run;                       // the group's first slot (fast path) / its write cursor
+            run += c;
+        }
+        if (threadIdx.x == 0) group_off[G] = Lq;            // every query is in exactly one group
+    }
+    __syncthreads();
+    if (regs) {
+#pragma unroll
+        for (int i = 0; i < kRegQ; ++i)
+            if (i < K) {
+                if (q0 + i < Lq) perm[s_cnt[gr[i] & 0xFFFu] + (int)(gr[i] >> 12)] = q0 + i;
+            }
+    } else {
+        for (int q = threadIdx.x; q < Lq; q += kSchedThreads) {
+            const float2 r1 = *reinterpret_cast<const float2 *>(ref + (int64_t)q * 2);
+            perm[atomicAdd(&cnt[group_of(r1.x, r1.y, sx, sy, ntx, nty)], 1)] = q;
+        }
     }
 }
 
@@ -256,10 +340,16 @@ int64_t win_gmax(int64_t S) { return S / 8 + 2; }        // groups of 8 x 8 pixe
 
 template <typename VT, typename PT>
 int launch(const void *value, const void *off, const void *logit, int64_t os, int64_t ls, const float *ref, const int64_t *shapes,
-           const int64_t *lsi, int64_t N, int64_t S, int64_t M, int64_t Lq, int halo, void *ws, void *out, hipStream_t st) {
+           const int64_t *lsi, int64_t N, int64_t S, int64_t M, int64_t Lq, int halo, void *ws, bool ws_ready, void *out,
+           hipStream_t st) {
     const int Gmax = (int)win_gmax(S);
-    hipLaunchKernelGGL(msda_win_schedule, dim3(1), dim3(kSchedThreads), 0, st, ref, shapes, lsi, (int)Lq, S, Gmax, (unsigned char *)ws);
-    if (int rc = check_launch("msda window schedule launch")) return rc;
+    if (!ws_ready) {
+        constexpr int sched_lds = (kLdsGroups + kSchedThreads) * 4 + kRegQ * kSchedThreads * 2;
+        if (int rc = allow_dynamic_lds((const void *)msda_win_schedule, sched_lds, "msda window schedule")) return rc;
+        hipLaunchKernelGGL(msda_win_schedule, dim3(1), dim3(kSchedThreads), sched_lds, st, ref, shapes, lsi, (int)Lq, S, Gmax,
+                           (unsigned char *)ws);
+        if (int rc = check_launch("msda window schedule launch")) return rc;
+    }
     const int side = kTile + 2 * (halo + 1);
     const int smem = side * side * kD * (int)sizeof(VT);
     if (smem > 64 * 1024) return fail(VAH_E_SHAPE, "msda fused forward (windows): a halo of %d pixels needs too much LDS", halo);
@@ -292,7 +382,7 @@ int64_t vah_msda_win_ws_bytes(int64_t S, int64_t Lq) {
 int vah_msda_fused_forward_win(const void *value, int value_dtype, const int64_t *shapes, const int64_t *lsi, const void *offsets,
                                const void *logits, int param_dtype, int64_t offsets_stride, int64_t logits_stride, const float *ref,
                                int64_t N, int64_t S, int64_t M, int64_t D, int64_t Lq, int64_t P, int64_t halo, void *ws,
-                               int64_t ws_bytes, void *out, void *stream) {
+                               int64_t ws_bytes, int ws_holds_schedule, void *out, void *stream) {
     using namespace vah;
     clear_error();
     const char *fn = "vah_msda_fused_forward_win";
@@ -314,7 +404,7 @@ int vah_msda_fused_forward_win(const void *value, int value_dtype, const int64_t
                       4 * (N * S * M * D + 3 * N * Lq * M * P + N * Lq * M * D));
 #define VAH_CASE(VT, VC, PT, PC)                                                                                     \
     if (value_dtype == VC && param_dtype == PC)                                                                      \
-        return launch<VT, PT>(value, offsets, logits, os, ls, ref, shapes, lsi, N, S, M, Lq, (int)halo, ws, out, st)
+        return launch<VT, PT>(value, offsets, logits, os, ls, ref, shapes, lsi, N, S, M, Lq, (int)halo, ws, ws_holds_schedule != 0, out, st)
     VAH_CASE(float, 0, float, 0);
     VAH_CASE(__bf16, 1, __bf16, 1);
     VAH_CASE(__bf16, 1, float, 0);

@@ -96,10 +96,13 @@ static_assert(sizeof(PlanDev) <= kPlanBytes, "plan header");
 // One work item of the tile pass - a list, or one slice of a shared list - as the plan kernel writes it and a wave of
 // the tile pass reads it with one scalar load (decoding an item number cost five integer divisions per item).
 // Item order: a GROUP is one tile of one image with all its heads and slices (M * ksplit items that read the same
-// query rows); groups are numbered level block by level block (longest lists first) and dealt round-robin to the 8
-// XCDs (group % 8 = blockIdx % 8 of the waves that take it), so every XCD gets the same mix of long and short lists
-// and the heads of a tile share one L2; within an XCD the items - its groups in order, m-major inside a group - are
-// dealt to the XCD's waves with stride gridDim / 8.  Placement only affects speed.
+// query rows); groups are numbered level block by level block (longest lists first), image by image and tile row by
+// tile row, and every level block is cut into 8 contiguous ranges, one per XCD (XCD = blockIdx % 8 of the waves that
+// take it): every XCD gets the same mix of long and short lists, and the same band of every level - a query row is
+// named by ~2 neighbouring tiles per level and by the same place on every level, so most of its re-reads (grad_out row,
+// offsets / logits row) hit the L2 that already holds it (dealt round-robin, every tile's neighbours sat on other XCDs
+// and each duplicate went to the fabric: 119 MiB FETCH_SIZE per extractor call).  Within an XCD the items - its groups
+// in order, m-major inside a group - are dealt to the XCD's waves with stride gridDim / 8.  Placement only affects speed.
 struct ItemDesc {
     int n, ml;          // image; head | level << 16
     int tyx;            // tile row | tile column << 16
@@ -129,7 +132,7 @@ int make_bounds(const char *fn, int64_t N, int64_t S, int64_t M, int64_t L, int6
     b->nlists_max = N * M * b->Tmax;
     b->nslabs_max = N * M * (L * (Lq / 128 + 1));
     const int64_t items_max = N * M * (b->Tmax + L * (Lq / 256 + 1));
-    b->items_per_xcd = items_max / 8 + L * M * (Lq / 512 + 2) + 8;      // round-robin groups: at most one group more per level block
+    b->items_per_xcd = items_max / 8 + L * M * (Lq / 512 + 2) + 8;      // an eighth of every level block: at most one group more per block
     if (b->nlists_max >= ((int64_t)1 << 26) || N * M * b->ETmax >= ((int64_t)1 << 31) || items_max >= ((int64_t)1 << 30) ||
         b->nslabs_max >= ((int64_t)1 << 30))
         return fail(VAH_E_UNSUPPORTED, "%s: problem too large for the tiled path", fn);
@@ -246,10 +249,7 @@ __global__ __launch_bounds__(256) void msda_plan(const int64_t *__restrict__ sha
             const int ng = b < L ? N * g.ntiles[l] : 0, per = M * (b < L ? g.ksplit[l] : 1);
             g.gb[b] = gb, g.ib[b] = nw;
 #pragma unroll
-            for (int x = 0; x < 8; ++x) {
-                const int f = gb + ((x - gb) & 7);                        // smallest group >= gb with group % 8 == x
-                g.xcount[x] += (f < gb + ng ? (gb + ng - f + 7) >> 3 : 0) * per;
-            }
+            for (int x = 0; x < 8; ++x) g.xcount[x] += ((((x + 1) * ng) >> 3) - ((x * ng) >> 3)) * per;   // eighth x of the block
             gb += ng;
             nw += ng * per;
         }
@@ -286,17 +286,18 @@ __device__ __forceinline__ void write_item(const PlanDev &g, const Bounds &bd, I
     const int m = (int)(r_ % (unsigned)M);
     r_ /= (unsigned)M;                                  // group inside the block = n * ntiles + tile
     const int tl = (int)(r_ % (unsigned)nt), n = (int)(r_ / (unsigned)nt);
-    const int grp = gb_b + (int)r_, x = grp & 7;
-    // local position on XCD x: items of earlier blocks + groups of this block before this one
+    // XCD of the group: eighth x of its level block, groups [x * ng / 8, (x + 1) * ng / 8)
+    const int ng_b = (blk == 0 ? g.gb[1] : blk == 1 ? g.gb[2] : blk == 2 ? g.gb[3] : g.gb[4]) - gb_b;
+    const int x = (int)((8u * (r_ + 1u) + (unsigned)ng_b - 1u) / (unsigned)ng_b) - 1;
+    // local position on XCD x: its items of earlier blocks + its groups of this block before this one
     int pos = 0;
 #pragma unroll
     for (int b = 0; b < kMaxL; ++b) {
-        const int f = g.gb[b] + ((x - g.gb[b]) & 7);
-        const int c = f < g.gb[b + 1] ? (g.gb[b + 1] - f + 7) >> 3 : 0;
+        const int ng = g.gb[b + 1] - g.gb[b];
         const int lb = g.wgorder[b];
         const int per = M * (b < g.L ? (lb == 0 ? g.ksplit[0] : lb == 1 ? g.ksplit[1] : lb == 2 ? g.ksplit[2] : g.ksplit[3]) : 1);
-        if (b < blk) pos += c * per;
-        if (b == blk) pos += ((grp - f) >> 3) * per;
+        if (b < blk) pos += ((((x + 1) * ng) >> 3) - ((x * ng) >> 3)) * per;
+        if (b == blk) pos += ((int)r_ - ((x * ng) >> 3)) * per;
     }
     pos += m * ks + j;
     ItemDesc d;

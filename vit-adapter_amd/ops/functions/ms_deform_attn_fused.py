@@ -32,7 +32,7 @@ WIN_HALO = int(os.environ.get('VAH_MSDA_WIN_HALO', 5))
 def window_forward(n_levels, n_points, ref_levels, Lq):
     """The LDS-window forward serves single-level calls with batch-shared reference points (VAH_MSDA_FWD_WIN=0: the
     8-lane gather kernel).  Its schedule is built on the device from the reference points and the device copies of the
-    level geometry: nothing is read back, nothing is cached by tensor identity."""
+    level geometry: nothing is read back (see _window_workspace for how one forward's six calls share it)."""
     return (n_levels == 1 and n_points == 4 and ref_levels == 1 and Lq <= (1 << 18)
             and os.environ.get('VAH_MSDA_FWD_WIN', '1') != '0')
 
@@ -68,20 +68,53 @@ def tiled_backward(n_levels, n_points):
     return n_points == 4 and 1 <= n_levels <= 4 and os.environ.get('VAH_MSDA_TILED', '1') != '0'
 
 
-def fused_forward(value, spatial_shapes, level_start_index, offsets, logits, o_s, l_s, ref):
-    """The fused forward kernels on raw row-strided offsets / logits (see _row_strides); ref (Lq, 1 | L, 2) fp32."""
+class _WinSchedule:
+    """A window-forward workspace that still holds its schedule, riding on the caller's reference_points tensor."""
+    __slots__ = ('ws', 'key', 'shapes', 'lsi')
+
+
+def _window_workspace(carrier, token, spatial_shapes, level_start_index, S, Lq, device):
+    """-> (ws, ws_bytes, holds_schedule).  The schedule of the window forward depends on the reference points and the level
+    geometry only, and the adapter calls its extractor six times per forward (and six more in a checkpointed backward)
+    with ONE set of deform inputs: the workspace rides on the reference_points tensor OBJECT the caller passed
+    (`carrier`) and is handed to the next call that comes with the same objects, unmodified (tensor version counters),
+    on the same stream, in the same pass (`token`: the caller's forward epoch + capture state).  No table keyed by id():
+    the attribute dies with the tensor, a fresh tensor simply has none; nothing is read back from the device."""
+    import weakref
+    ws_bytes = _vah.lib.vah_msda_win_ws_bytes(S, Lq)
+    if ws_bytes < 0:
+        return None, ws_bytes, False
+    key = None
+    if carrier is not None and token is not None:
+        key = (token, carrier._version, spatial_shapes._version, level_start_index._version, S, Lq, ws_bytes,
+               _vah.raw_stream(device), torch.cuda.is_current_stream_capturing())
+        sch = getattr(carrier, '_vah_win_schedule', None)
+        if (sch is not None and sch.key == key and sch.shapes() is spatial_shapes and sch.lsi() is level_start_index
+                and sch.ws.device == device):
+            return sch.ws, ws_bytes, True
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=device)
+    if key is not None:
+        sch = _WinSchedule()
+        sch.ws, sch.key = ws, key
+        sch.shapes, sch.lsi = weakref.ref(spatial_shapes), weakref.ref(level_start_index)
+        carrier._vah_win_schedule = sch
+    return ws, ws_bytes, False
+
+
+def fused_forward(value, spatial_shapes, level_start_index, offsets, logits, o_s, l_s, ref, carrier=None, token=None):
+    """The fused forward kernels on raw row-strided offsets / logits (see _row_strides); ref (Lq, 1 | L, 2) fp32.
+    carrier / token: see _window_workspace (None: the window schedule is built in this call)."""
     N, S, M, D = value.shape
     _, Lq, _, L, P, _ = offsets.shape
     out = torch.empty((N, Lq, M * D), dtype=value.dtype, device=value.device)
     if window_forward(L, P, ref.shape[1], Lq):
-        ws_bytes = _vah.lib.vah_msda_win_ws_bytes(S, Lq)
-        if ws_bytes >= 0:
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=value.device)
+        ws, ws_bytes, ready = _window_workspace(carrier, token, spatial_shapes, level_start_index, S, Lq, value.device)
+        if ws is not None:
             with _vah.on(value.device):
                 rc = _vah.lib.vah_msda_fused_forward_win(
                     value.data_ptr(), _DT[value.dtype], spatial_shapes.data_ptr(), level_start_index.data_ptr(),
                     offsets.data_ptr(), logits.data_ptr(), _DT[offsets.dtype], o_s, l_s, ref.data_ptr(),
-                    N, S, M, D, Lq, P, WIN_HALO, ws.data_ptr(), ws_bytes, out.data_ptr(), _vah.raw_stream(value.device))
+                    N, S, M, D, Lq, P, WIN_HALO, ws.data_ptr(), ws_bytes, int(ready), out.data_ptr(), _vah.raw_stream(value.device))
             _vah.check(rc, 'vah_msda_fused_forward_win')
             return out
     with _vah.on(value.device):

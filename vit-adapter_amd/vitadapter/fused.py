@@ -649,7 +649,7 @@ class _MSDAPairCore(torch.autograd.Function):
         logits = yv[..., 2 * L * P:]
         value = value.contiguous()
         refc = ref.detach().float().contiguous().view(Lq, -1, 2)
-        out = mf.fused_forward(value, shapes, lsi, offsets, logits, PS, PS, refc)
+        out = mf.fused_forward(value, shapes, lsi, offsets, logits, PS, PS, refc, carrier=ref, token=BF16_COPIES.epoch)
         ctx.save_for_backward(x2, w, y, value, shapes, lsi, refc, perm)
         ctx.dims = (N, Lq, M, L, P, wa.shape[0])
         ctx.in_shape, ctx.in_dtype = query.shape, query.dtype
