@@ -38,6 +38,8 @@ Rank 0 prints ONE JSON line with the contract fields plus
 import argparse
 import json
 import os
+
+os.environ.setdefault('MIOPEN_FIND_MODE', '2')     # UPerHead row: MIOpen convolutions of new shapes without an exhaustive search
 import sys
 import time
 
@@ -86,6 +88,8 @@ def parse():
                          '"none" = no events)')
     ap.add_argument('--boundary-iters', type=int, default=20,
                     help='iterations of the fp32 boundary-kernel measurement after the timed region (0 = skip)')
+    ap.add_argument('--consumer-iters', type=int, default=5,
+                    help='iterations of the pixel-decoder encoder / UPerHead rows after the timed region (0 = skip)')
     ap.add_argument('--mock-step', action='store_true',
                     help='CPU rehearsal of the launch path only (rank spawn, process group over gloo, barrier, '
                          'max-over-ranks, the one JSON line) around a toy step; used by tests/test_bench_launch_cpu.py, '
@@ -234,6 +238,72 @@ def boundary_kernels(dev, iters):
             if r['calls']:
                 rows['%s[%s]' % (name, cfg)] = kernel_row(r, 1)
         del v, s, i, l, a, g
+    return rows
+
+
+def consumer_rows(dev, iters):
+    """The two consumers of the backbone's maps that BASELINE configs[3] / configs[4] name, as rows beside the backbone's
+    (they are not part of the timed step: the metric is the backbone's): the 6-layer deformable encoder of Mask2Former's
+    pixel decoder at configs[4]'s per-GPU shapes (800 x 1344, batch 1: levels 25x42, 50x84, 100x168, 256 channels, 8
+    heads; vitadapter/pixel_decoder.py) and UPerHead at configs[3]'s (640 x 640, batch 2: four 1024-channel maps at
+    strides 4..32, 512 channels inside, 150 classes; vitadapter/heads.py), forward + backward under bf16 autocast, timed
+    with HIP events on the launch stream; the MSDA launches inside the encoder with the library's own events."""
+    import _vah
+    from vitadapter.heads import UPerHead
+    from vitadapter.pixel_decoder import MSDeformAttnEncoder, encoder_inputs
+    rows = {}
+
+    def timed(fn, n):
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / n
+
+    torch.manual_seed(0)
+    enc = MSDeformAttnEncoder().to(dev).train()
+    with torch.no_grad():                           # the zero-initialised offsets / weights Linear as after some training
+        for layer in enc.layers:
+            layer.attentions[0].sampling_offsets.weight.normal_(0, 0.02)
+            layer.attentions[0].attention_weights.weight.normal_(0, 0.05)
+    shapes = [(25, 42), (50, 84), (100, 168)]
+    query, pos, ref, ss, lsi = encoder_inputs(shapes, 1, 256, dev)
+    query.requires_grad_(True)
+
+    def enc_step():
+        enc.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out = enc(query=query, query_pos=pos, spatial_shapes=ss, reference_points=ref, level_start_index=lsi)
+        out.float().mean().backward()
+
+    ms = timed(enc_step, iters)
+    _vah.prof_enable(True, 'msda_')
+    for _ in range(iters):
+        enc_step()
+    torch.cuda.synchronize()
+    _vah.prof_enable(False)
+    rows['pixel_decoder_encoder[cfg4]'] = {'what': '6 layers, Lq = S = %d, batch 1, 256 ch, 8 heads, 3 levels, fwd+bwd, bf16 autocast'
+                                           % sum(h * w for h, w in shapes), 'ms': round(ms, 3)}
+    for name, r in _vah.prof_report().items():
+        if r['calls']:
+            rows['%s[cfg4_pixdec]' % name] = kernel_row(r, iters)
+    del enc, query, pos, ref
+    head = UPerHead(in_channels=(1024,) * 4, channels=512, num_classes=150).to(dev).train()
+    feats = [torch.randn(2, 1024, 160 >> i, 160 >> i, device=dev, requires_grad=True) for i in range(4)]
+
+    def head_step():
+        head.zero_grad(set_to_none=True)
+        with torch.autocast('cuda', dtype=torch.bfloat16):
+            out = head(feats)
+        out.float().mean().backward()
+
+    rows['uper_head[cfg3]'] = {'what': 'UPerHead 4 x 1024 ch in (160..20 px), 512 ch, 150 classes, batch 2, fwd+bwd, bf16 autocast '
+                                       '(MIOpen / hipBLASLt convolutions)', 'ms': round(timed(head_step, iters), 3)}
     return rows
 
 
@@ -520,6 +590,8 @@ def main():
                                       'frac_of_mfma_peak': round(fl / (ms * 1e-3) / MFMA_PEAK, 4)}
         if args.boundary_iters > 0 and world == 1:
             kernels.update(boundary_kernels(dev, args.boundary_iters))
+            if args.consumer_iters > 0:
+                kernels.update(consumer_rows(dev, args.consumer_iters))
         line = {
             'metric': ('images/sec ViT-Adapter-B 1024x1024 fwd+bwd (+AdamW step)' if (args.preset, H, W) == ('base_det', 1024, 1024)
                        else 'images/sec %s %dx%d fwd+bwd (+AdamW step)' % (args.preset, H, W)),

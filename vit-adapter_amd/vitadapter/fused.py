@@ -533,14 +533,14 @@ class _LinearPairBF16(torch.autograd.Function):
     two input gradients."""
 
     @staticmethod
-    def forward(ctx, x, wa, ba, wb, bb, pair):
+    def forward(ctx, x, wa, ba, wb, bb, pair, f32_out=False):
         K = x.shape[-1]
         x2 = x.reshape(-1, K)
         if x2.dtype != torch.bfloat16:
             x2 = x2.to(torch.bfloat16)
         x2 = x2.contiguous()
         w, bias = pair
-        y = gemm_bf16(x2, w, trans_b=True, bias=bias)
+        y = gemm_bf16(x2, w, trans_b=True, bias=bias, out_dtype=torch.float32 if f32_out else torch.bfloat16)
         na = wa.shape[0]
         ctx.save_for_backward(x2, w)
         ctx.na, ctx.in_shape, ctx.in_dtype = na, x.shape, x.dtype
@@ -575,18 +575,25 @@ class _LinearPairBF16(torch.autograd.Function):
                     _vah.check(_vah.lib.vah_colsum_bf16(g.data_ptr(), R, na + nb, gbias.data_ptr(), ws.data_ptr(),
                                                         _stream(g)), 'colsum')
         return (gx, gw[:na] if gw is not None else None, gbias[:na] if gbias is not None else None,
-                gw[na:] if gw is not None else None, gbias[na:] if gbias is not None else None, None)
+                gw[na:] if gw is not None else None, gbias[na:] if gbias is not None else None, None, None)
 
 
-def linear_pair(lin_a, lin_b, x):
-    """``(lin_a(x), lin_b(x))`` for two nn.Linear layers on the same input."""
+def linear_pair(lin_a, lin_b, x, f32_out=False):
+    """``(lin_a(x), lin_b(x))`` for two nn.Linear layers on the same input.  f32_out: the outputs straight from the fp32
+    accumulators (MSDeformAttn's sampling offsets: the reference keeps them in fp32, and d(out)/d(location) jumps at
+    integer pixel coordinates, so 8-bit offsets cost the upstream gradients 0.3 - 0.7 of relative L2 on small maps)."""
     wa, wb = lin_a.weight, lin_b.weight
     if (ENABLED['linear'] and ENABLED['linear_pair'] and x.is_cuda and _bf16_autocast() and wa.dtype == torch.float32
             and wb.dtype == torch.float32 and lin_a.bias is not None and lin_b.bias is not None
             and x.dtype in (torch.bfloat16, torch.float32) and (wa.shape[0] + wb.shape[0]) % 8 == 0
             and wa.shape[1] % 8 == 0 and wa.shape[1] == wb.shape[1] and x.numel() > 0
             and type(lin_a) is torch.nn.Linear and type(lin_b) is torch.nn.Linear):
-        return _LinearPairBF16.apply(x, wa, lin_a.bias, wb, lin_b.bias, PAIR_COPIES.get(lin_a, lin_b))
+        return _LinearPairBF16.apply(x, wa, lin_a.bias, wb, lin_b.bias, PAIR_COPIES.get(lin_a, lin_b), f32_out)
+    if f32_out and x.is_cuda and _bf16_autocast():
+        # widths the paired GEMM does not take (a single deformable head: 8 + 4 outputs): two plain fp32 Linears
+        with torch.autocast('cuda', enabled=False):
+            xf = x.float()
+            return torch.nn.functional.linear(xf, wa.float(), lin_a.bias), torch.nn.functional.linear(xf, wb.float(), lin_b.bias)
     return linear(lin_a, x), linear(lin_b, x)
 
 
