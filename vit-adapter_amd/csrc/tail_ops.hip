@@ -37,6 +37,7 @@ struct Operands {
     int rows_per_block, chunks;         // chunks of rows per plane
     int relu, y_bf16, dy_bf16;          // ReLU fused behind the normalisation; dtypes of y and dy
     const float *shift;                 // optional per-channel constant added to the sum (conv biases)
+    unsigned quad_magic;                // floor(2^32 / (W / 4)) + 1: item -> (row, quad) by one v_mul_hi (items < 2^16)
 };
 
 struct Tap {
@@ -164,19 +165,43 @@ __device__ __forceinline__ float4 sum4(const Operands &o, int64_t plane, int y, 
             t.z += xs.z;
             t.w += xs.w;
         } else {
-            const float inv2s = 0.5f / (float)sc;
             float u[4];
+            // The four pixels start at a multiple of 4, so for s = 2 and s = 4 which low-res column pair a pixel reads and
+            // with which weight is the same for every quad: constants instead of shifts, masks and 16 selects per quad
+            // (this pass is VALU-bound: the statistics pass over the stride-4 level took as long as the normalise pass,
+            // which also WRITES 403 MB).  Other scales take the general form.
+            if (sc == 4) {                  // columns b, b, b + 1, b + 1 of (c[0..2]); weights 5/8, 7/8, 1/8, 3/8
+                const float t0 = c0[0] + 0.625f * (c0[1] - c0[0]), b0 = c1[0] + 0.625f * (c1[1] - c1[0]);
+                const float t1 = c0[0] + 0.875f * (c0[1] - c0[0]), b1 = c1[0] + 0.875f * (c1[1] - c1[0]);
+                const float t2 = c0[1] + 0.125f * (c0[2] - c0[1]), b2 = c1[1] + 0.125f * (c1[2] - c1[1]);
+                const float t3 = c0[1] + 0.375f * (c0[2] - c0[1]), b3 = c1[1] + 0.375f * (c1[2] - c1[1]);
+                u[0] = t0 + ty.w1 * (b0 - t0);
+                u[1] = t1 + ty.w1 * (b1 - t1);
+                u[2] = t2 + ty.w1 * (b2 - t2);
+                u[3] = t3 + ty.w1 * (b3 - t3);
+            } else if (sc == 2) {           // columns b, b + 1, b + 1, b + 2; weights 3/4, 1/4, 3/4, 1/4
+                const float t0 = c0[0] + 0.75f * (c0[1] - c0[0]), b0 = c1[0] + 0.75f * (c1[1] - c1[0]);
+                const float t1 = c0[1] + 0.25f * (c0[2] - c0[1]), b1 = c1[1] + 0.25f * (c1[2] - c1[1]);
+                const float t2 = c0[1] + 0.75f * (c0[2] - c0[1]), b2 = c1[1] + 0.75f * (c1[2] - c1[1]);
+                const float t3 = c0[2] + 0.25f * (c0[3] - c0[2]), b3 = c1[2] + 0.25f * (c1[3] - c1[2]);
+                u[0] = t0 + ty.w1 * (b0 - t0);
+                u[1] = t1 + ty.w1 * (b1 - t1);
+                u[2] = t2 + ty.w1 * (b2 - t2);
+                u[3] = t3 + ty.w1 * (b3 - t3);
+            } else {
+                const float inv2s = 0.5f / (float)sc;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int nk = nx0 + 2 * k, ik = (nk >> sh1) - bcol;      // 0, 1 or 2
-                const float w1 = (float)(nk & mask) * inv2s;
-                const float a0 = ik == 0 ? c0[0] : (ik == 1 ? c0[1] : c0[2]);
-                const float a1 = ik == 0 ? c0[1] : (ik == 1 ? c0[2] : c0[3]);
-                const float b0 = ik == 0 ? c1[0] : (ik == 1 ? c1[1] : c1[2]);
-                const float b1 = ik == 0 ? c1[1] : (ik == 1 ? c1[2] : c1[3]);
-                const float top = a0 + w1 * (a1 - a0);
-                const float bot = b0 + w1 * (b1 - b0);
-                u[k] = top + ty.w1 * (bot - top);
+                for (int k = 0; k < 4; ++k) {
+                    const int nk = nx0 + 2 * k, ik = (nk >> sh1) - bcol;      // 0, 1 or 2
+                    const float w1 = (float)(nk & mask) * inv2s;
+                    const float a0 = ik == 0 ? c0[0] : (ik == 1 ? c0[1] : c0[2]);
+                    const float a1 = ik == 0 ? c0[1] : (ik == 1 ? c0[2] : c0[3]);
+                    const float b0 = ik == 0 ? c1[0] : (ik == 1 ? c1[1] : c1[2]);
+                    const float b1 = ik == 0 ? c1[1] : (ik == 1 ? c1[2] : c1[3]);
+                    const float top = a0 + w1 * (a1 - a0);
+                    const float bot = b0 + w1 * (b1 - b0);
+                    u[k] = top + ty.w1 * (bot - top);
+                }
             }
             t.x += u[0];
             t.y += u[1];
@@ -208,7 +233,7 @@ __global__ __launch_bounds__(256) void tail_stats_kernel(Operands o, float *__re
     const int wv4 = o.W >> 2;
     float s1 = 0.f, s2 = 0.f;
     for (int i = threadIdx.x; i < (r1 - r0) * wv4; i += 256) {
-        const int y = r0 + i / wv4, x4 = (i % wv4) * 4;
+        const int iy = wv4 == 1 ? i : (int)__umulhi((unsigned)i, o.quad_magic), y = r0 + iy, x4 = (i - iy * wv4) * 4;
         const float4 t = sum4(o, plane, y, x4);
         s1 += (t.x + t.y) + (t.z + t.w);
         s2 += (t.x * t.x + t.y * t.y) + (t.z * t.z + t.w * t.w);
@@ -235,7 +260,7 @@ __global__ __launch_bounds__(256) void tail_apply_kernel(Operands o, const float
     const float sh = (beta ? beta[c] : 0.f) - mean[c] * sc;
     const float lo = o.relu ? 0.f : -INFINITY;
     for (int i = threadIdx.x; i < (r1 - r0) * wv4; i += 256) {
-        const int yy = r0 + i / wv4, x4 = (i % wv4) * 4;
+        const int iy = wv4 == 1 ? i : (int)__umulhi((unsigned)i, o.quad_magic), yy = r0 + iy, x4 = (i - iy * wv4) * 4;
         const float4 t = sum4(o, plane, yy, x4);
         store4(y, (plane * o.H + yy) * o.W + x4, o.y_bf16,
                make_float4(fmaxf(t.x * sc + sh, lo), fmaxf(t.y * sc + sh, lo), fmaxf(t.z * sc + sh, lo),
@@ -273,7 +298,7 @@ __global__ __launch_bounds__(256) void tail_bwd_stats_kernel(Operands o, const f
     const float sc = rs * (gamma ? gamma[c] : 1.f), sh = (beta ? beta[c] : 0.f) - mu * sc;
     float s1 = 0.f, s2 = 0.f;
     for (int i = threadIdx.x; i < (r1 - r0) * wv4; i += 256) {
-        const int yy = r0 + i / wv4, x4 = (i % wv4) * 4;
+        const int iy = wv4 == 1 ? i : (int)__umulhi((unsigned)i, o.quad_magic), yy = r0 + iy, x4 = (i - iy * wv4) * 4;
         Raw4 rdy;
         const float4 t = sum4(o, plane, yy, x4, dy, &rdy);
         const float4 g = grad4(o, rdy, t, sc, sh);
@@ -313,7 +338,7 @@ __global__ __launch_bounds__(256) void tail_bwd_apply_kernel(Operands o, const f
     const float sh = (beta ? beta[c] : 0.f) - mu * k;
     const bool want_lo = dxlo != nullptr && o.x != nullptr;
     for (int i = threadIdx.x; i < rows * wv4; i += 256) {
-        const int yy = r0 + i / wv4, x4 = (i % wv4) * 4;
+        const int iy = wv4 == 1 ? i : (int)__umulhi((unsigned)i, o.quad_magic), yy = r0 + iy, x4 = (i - iy * wv4) * 4;
         const int64_t idx = (plane * o.H + yy) * o.W + x4;
         Raw4 rdy;
         const float4 t = sum4(o, plane, yy, x4, dy, &rdy);
@@ -591,6 +616,9 @@ int fill_operands(const char *fn, Operands &o, const void *a, int a_bf16, const 
         o.rows_per_block = (o.rows_per_block + 2 * scale - 1) / (2 * scale) * (2 * scale);
         o.chunks = (int)((H + o.rows_per_block - 1) / o.rows_per_block);
     }
+    // exact for items < 2^16 (a block has rows_per_block * W / 4 <= 8192 / 4 + 2 * scale * W / 4 of them)
+    if ((int64_t)o.rows_per_block * (W / 4) >= 65536) return fail(VAH_E_SHAPE, "%s: row too wide for the tiling", fn);
+    o.quad_magic = W / 4 > 1 ? (unsigned)(((uint64_t)1 << 32) / (uint64_t)(W / 4)) + 1u : 0u;      // one quad per row: no division
     return VAH_OK;
 }
 

@@ -614,11 +614,16 @@ class _PairCoreCopies:
         na, nb = a.weight.shape[0], b.weight.shape[0]
         po, pl = na // M, nb // M
         dev = a.weight.device
-        perm = e[3] if (e is not None and e[3].device == dev) else torch.cat(
-            [torch.cat((torch.arange(m * po, (m + 1) * po), na + torch.arange(m * pl, (m + 1) * pl))) for m in range(M)]).to(dev)
+        if e is not None and e[3][0].device == dev:
+            perm = e[3]
+        else:               # (permutation, its inverse): made once per module and device, not per call
+            fw = torch.cat([torch.cat((torch.arange(m * po, (m + 1) * po), na + torch.arange(m * pl, (m + 1) * pl))) for m in range(M)])
+            inv = torch.empty_like(fw)
+            inv[fw] = torch.arange(fw.numel())
+            perm = (fw.to(dev), inv.to(dev))
         with torch.no_grad():
-            w = torch.cat([a.weight.detach(), b.weight.detach()], 0).index_select(0, perm).to(torch.bfloat16)
-            bias = torch.cat([a.bias.detach(), b.bias.detach()], 0).float().index_select(0, perm)
+            w = torch.cat([a.weight.detach(), b.weight.detach()], 0).index_select(0, perm[0]).to(torch.bfloat16)
+            bias = torch.cat([a.bias.detach(), b.bias.detach()], 0).float().index_select(0, perm[0])
         if len(self.entries) > 1024:
             self.entries.clear()
         self.entries[key] = (epoch, w, bias, perm, weakref.ref(a.weight))
@@ -657,7 +662,7 @@ class _MSDAPairCore(torch.autograd.Function):
         value = value.contiguous()
         refc = ref.detach().float().contiguous().view(Lq, -1, 2)
         out = mf.fused_forward(value, shapes, lsi, offsets, logits, PS, PS, refc, carrier=ref, token=BF16_COPIES.epoch)
-        ctx.save_for_backward(x2, w, y, value, shapes, lsi, refc, perm)
+        ctx.save_for_backward(x2, w, y, value, shapes, lsi, refc, perm[1])
         ctx.dims = (N, Lq, M, L, P, wa.shape[0])
         ctx.in_shape, ctx.in_dtype = query.shape, query.dtype
         return out
@@ -665,7 +670,7 @@ class _MSDAPairCore(torch.autograd.Function):
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, gout):
-        x2, w, y, value, shapes, lsi, refc, perm = ctx.saved_tensors
+        x2, w, y, value, shapes, lsi, refc, inv = ctx.saved_tensors
         N, Lq, M, L, P, na = ctx.dims
         S, D = value.shape[1], value.shape[3]
         PS = 3 * L * P
@@ -688,8 +693,6 @@ class _MSDAPairCore(torch.autograd.Function):
                 gx = gx.to(ctx.in_dtype)
         if any(ctx.needs_input_grad[5:9]):
             gwp, gbp = _wgrad_bgrad(g, x2)
-            inv = torch.empty_like(perm)
-            inv[perm] = torch.arange(perm.numel(), device=perm.device)
             gw, gbias = gwp.index_select(0, inv), gbp.index_select(0, inv)
         return (gx, grad_value if ctx.needs_input_grad[1] else None, None, None, None,
                 gw[:na] if gw is not None else None, gbias[:na] if gbias is not None else None,
