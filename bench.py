@@ -575,8 +575,9 @@ def main():
                         'traffic': pmc_traffic(dom, args, preset_kw),
                         'avg_launch_us': msda[dom]['avg_us'],
                         'algorithmic_bytes_per_launch': msda[dom]['bytes_per_launch'],
-                        'bytes_are': 'moved for the IO dtypes of the launch: value, out / grad_out, offsets, logits and their '
-                                     'gradients in %s (grad_value too: the tile pass stores it in the value dtype)' % args.dtype,
+                        'bytes_are': 'moved for the IO dtypes of the launch: value, out / grad_out and grad_value in %s (the tile pass '
+                                     'stores grad_value in the value dtype); under autocast the offsets / logits rows are the fp32 '
+                                     'output of their GEMM read in place, their gradients bf16 rows' % args.dtype,
                         'frac_fp32_definition': msda[dom].get('frac_fp32_definition')}
         for name, r in fam_prof.items():
             if r['calls'] and name not in kernels:
