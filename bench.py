@@ -17,8 +17,11 @@ three replays are timed (still warm-up), and the timed region runs the faster fo
 step) where the host is the longer pole - slow-CPU boxes, the 24-block presets - or the eager loop where the GPU is (it
 overlaps the weight-gradient GEMMs on a side stream, a captured graph does not).  HIP events cannot be read back from
 inside a graph, so after a replayed region the per-kernel rows are taken from K more EAGER steps of the same process
-(`config.hip_graph`, `config.hip_graph_probe`, `config.kernel_rows`).  `--hip-graph off` (and every N > 1 run: DDP's
-buckets are not captured) always times the eager loop with the events inside the timed region.
+(`config.hip_graph`, `config.hip_graph_probe`, `config.kernel_rows`).  N > 1 (round 3): the same - the captured step then
+holds DDP's bucketed all-reduces and the SyncBatchNorm statistics all-reduces (RCCL collectives are capturable; DDP is
+constructed and warmed up for 11 steps on the side stream, as torch asks); the ranks agree before the first replay, so a
+rank whose capture failed sends everyone to the eager loop.  `--hip-graph off` / `VAH_DP_GRAPH=0` time the eager loop with
+the events inside the timed region.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   "roofline":     the MSDA entry point with the largest total time in the timed region: bytes the
@@ -62,12 +65,14 @@ def parse():
     ap.add_argument('--preset', default='base_det', help='vitadapter preset (base_det = BASELINE configs[2])')
     ap.add_argument('--size', type=int, nargs=2, default=[1024, 1024], metavar=('H', 'W'))
     ap.add_argument('--hip-graph', default='auto', choices=['auto', 'on', 'off'],
-                    help='single GPU: capture one whole step (zero_grad, forward, backward, AdamW) into a HIP graph after the '
-                         'warm-up and time K replays of it (0.3 ms of host time per step instead of 20-70 ms); the per-kernel '
-                         'rows then come from K more EAGER steps right after the timed region, because HIP events cannot be '
-                         'read back from inside a graph.  auto: one GPU AND the eager loop measured host-bound during the '
-                         'warm-up (eager if the capture fails); never for N > 1 (DDP buckets are not captured); off: always '
-                         'the eager loop with the events inside the timed region')
+                    help='capture one whole step (zero_grad, forward, backward, AdamW - and, with a process group, DDP\'s bucketed '
+                         'all-reduces and the SyncBatchNorm statistics all-reduces: RCCL collectives are capturable) into a HIP '
+                         'graph after the warm-up and time K replays of it (0.3 ms of host time per step instead of 20-70 ms); the '
+                         'per-kernel rows then come from K more EAGER steps right after the timed region, because HIP events '
+                         'cannot be read back from inside a graph.  auto: replay if the capture succeeds ON EVERY RANK and three '
+                         'replays beat three eager steps (maximum over the ranks) during the warm-up, else the eager loop; '
+                         'VAH_DP_GRAPH=0 keeps steps with collectives eager; off: always the eager loop with the events inside '
+                         'the timed region')
     ap.add_argument('--no-checkpoint', action='store_true',
                     help='presets with with_cp=True (the large models: the reference recomputes activations to fit 32 GB '
                          'cards): keep the activations instead - 288 GB of HBM holds them, same arithmetic')
@@ -452,8 +457,20 @@ def main():
     torch.manual_seed(0)
     model = build_preset(args.preset, **({'with_cp': False} if args.no_checkpoint else {})).to(dev).train()
     n_params = sum(p.numel() for p in model.parameters())
-    net = dp.wrap(model, dev, bucket_cap_mb=64)
-    use_graph = args.hip_graph != 'off' and world == 1 and not args.no_optimizer
+    # A process group (N > 1, or one rank with VAH_ONE_RANK_GROUP=1): the step contains DDP's bucketed all-reduces and the
+    # SyncBatchNorm statistics all-reduces.  RCCL collectives are capturable; torch asks for the DDP constructor AND >= 11
+    # warm-up steps on the stream the capture will use.  VAH_DP_GRAPH=0: never capture a step that has collectives.
+    grouped = dist.is_initialized()
+    dp_graph = grouped and args.backend == 'nccl' and os.environ.get('VAH_DP_GRAPH', '1') != '0'
+    use_graph = args.hip_graph != 'off' and not args.no_optimizer and (not grouped or dp_graph)
+    side = torch.cuda.Stream() if use_graph else None
+    if grouped and use_graph:
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            net = dp.wrap(model, dev, bucket_cap_mb=64)
+        torch.cuda.current_stream().wait_stream(side)
+    else:
+        net = dp.wrap(model, dev, bucket_cap_mb=64)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-5, weight_decay=0.05, fused=True, capturable=use_graph)
     amp = torch.bfloat16 if args.dtype == 'bf16' else None
 
@@ -479,13 +496,20 @@ def main():
     probe = None
     if use_graph:
         # warm-up on a side stream (allocator pools, GEMM algorithm choices), then one captured step
-        side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(max(args.warmup, 3)):
+            for _ in range(max(args.warmup, 11 if grouped else 3)):
                 step()
         torch.cuda.current_stream().wait_stream(side)
         fence()
+
+        def agree(flag):
+            """Every rank replays or none does: a rank whose capture failed must not leave the others inside a collective."""
+            if not grouped:
+                return flag
+            t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(t.item())
 
         def wall(fn, n=3):
             torch.cuda.synchronize()
@@ -507,12 +531,20 @@ def main():
                 torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
             graph = torch.cuda.CUDAGraph()
             opt.zero_grad(set_to_none=True)
-            with torch.cuda.graph(graph):
-                graph_loss = step()
+            captured, why = True, None
+            try:
+                with torch.cuda.graph(graph):
+                    graph_loss = step()
+            except Exception as exc:                   # noqa: BLE001 - told to the other ranks below, then handled
+                captured, why = False, exc
+            torch.cuda.synchronize()
+            if not agree(captured):
+                raise why if why is not None else RuntimeError('another rank could not capture the step')
             fence()
             if eager_ms is not None:
-                probe = {'eager_ms': round(eager_ms, 3), 'graph_ms': round(1e3 * wall(graph.replay), 3)}
-                if probe['eager_ms'] <= probe['graph_ms']:
+                probe = {'eager_ms': round(dp.max_over_ranks(eager_ms, dev), 3),
+                         'graph_ms': round(dp.max_over_ranks(1e3 * wall(graph.replay), dev), 3)}
+                if probe['eager_ms'] <= probe['graph_ms']:          # the same numbers on every rank: the same decision
                     graph, use_graph = None, False          # no replay from here on
         except Exception as exc:                       # noqa: BLE001 - any capture failure: the eager loop below
             if args.hip_graph == 'on':
@@ -613,7 +645,7 @@ def main():
                        'kernel_rows': ('HIP events over %d eager steps right after the timed region (events cannot be read '
                                        'back from inside a graph)' % args.steps) if use_graph else 'HIP events inside the timed region',
                        'rccl_ranks': dist.get_world_size() if dist.is_initialized() else 1,
-                       'backend': args.backend if world > 1 else None,
+                       'backend': args.backend if dist.is_initialized() else None,
                        # hipBLASLt algorithms the dispatcher's whole-output check refused (csrc/gemm.hip)
                        'gemm_candidates_rejected': int(_vah.lib.vah_gemm_rejected_candidates())},
             'roofline': roofline,

@@ -84,3 +84,31 @@ def test_two_rank_ddp_on_gpu_matches_single_process(tmp_path):
     for k, v in model.state_dict().items():
         if 'running_' in k:                                      # SyncBN statistics span both ranks' images
             assert float((s0[k] - v.float().cpu()).abs().max()) <= 2e-2 * max(1.0, float(v.abs().max())), k
+
+
+@pytest.mark.timeout(900)
+def test_one_rank_rccl_step_with_collectives_is_captured_and_replayed(tmp_path):
+    """RCCL on the one GPU of the test box: VAH_ONE_RANK_GROUP=1 makes bench.py build the nccl (= RCCL) process group, wrap
+    the backbone in DDP and run the SyncBatchNorm statistics all-reduces for ONE rank, so the step that `--gpus N` times -
+    bucketed gradient all-reduces and per-layer statistics all-reduces inside a captured HIP graph, `--hip-graph on`: a
+    capture failure is an error - runs end to end: RCCL initialisation, DDP's bucket hooks under capture, the collectives
+    as graph nodes, K replays.  What one GPU cannot show is traffic between GPUs.  The replayed step must agree with the
+    eager step of the same process group (same loss, both finite) and report itself as replayed."""
+    import json
+    import subprocess
+    env = dict(os.environ, RANK='0', LOCAL_RANK='0', WORLD_SIZE='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
+               VAH_ONE_RANK_GROUP='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    common = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--preset', 'tiny_seg', '--size', '256', '256',
+              '--steps', '3', '--warmup', '2', '--cpu-baseline', 'none', '--boundary-iters', '0', '--family-steps', '0',
+              '--consumer-iters', '0']
+    lines = {}
+    for mode in ('on', 'off'):
+        res = subprocess.run(common + ['--hip-graph', mode], env=env, capture_output=True, text=True, timeout=420)
+        assert res.returncode == 0, res.stderr[-3000:]
+        lines[mode] = json.loads(res.stdout.strip().splitlines()[-1])
+    on, off = lines['on'], lines['off']
+    assert on['config']['hip_graph'] is True and off['config']['hip_graph'] is False
+    assert on['config']['rccl_ranks'] == 1 and on['config']['backend'] == 'nccl' and on['n_gpus'] == 1
+    assert on['value'] > 0 and off['value'] > 0
+    # a replayed step costs the host next to nothing; the eager one its ~1000 launches
+    assert on['host_enqueue_ms_per_step'] < 0.5 * on['ms_per_step'], on

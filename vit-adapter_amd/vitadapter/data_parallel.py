@@ -21,9 +21,10 @@ def init_from_env(backend=None):
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or one_rank_group()) and not dist.is_initialized():
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')     # dmabuf IPC only on this stack
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         kw = {}
@@ -33,9 +34,16 @@ def init_from_env(backend=None):
     return rank, local_rank, world
 
 
+def one_rank_group():
+    """VAH_ONE_RANK_GROUP=1: build the process group, the DDP wrapper and the SyncBatchNorm collectives even for ONE rank.
+    A one-GPU box can then run everything the N > 1 path runs - RCCL initialisation, DDP's bucket hooks, the statistics
+    all-reduces, their capture in a HIP graph - except the traffic between GPUs (tests/test_data_parallel_gpu.py)."""
+    return os.environ.get('VAH_ONE_RANK_GROUP', '0') == '1'
+
+
 def wrap(model, device=None, bucket_cap_mb=64):
     """DDP wrapper (identity when there is one process)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not one_rank_group()):
         return model
     ids = [device.index] if device is not None and device.type == 'cuda' else None
     return torch.nn.parallel.DistributedDataParallel(
