@@ -467,7 +467,7 @@ def main():
     if grouped and use_graph:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            net = dp.wrap(model, dev, bucket_cap_mb=64)
+            net = dp.wrap(model, dev, bucket_cap_mb=int(os.environ.get('VAH_DDP_BUCKET_MB', '64')))
         torch.cuda.current_stream().wait_stream(side)
     else:
         net = dp.wrap(model, dev, bucket_cap_mb=64)
