@@ -553,6 +553,7 @@ def main():
             graph, use_graph = None, False
             torch.cuda.synchronize()
     if graph is not None:
+        fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             graph.replay()
