@@ -84,6 +84,10 @@ def parse():
     ap.add_argument('--backend', default='nccl', choices=['nccl', 'gloo'],
                     help="'gloo' lets several ranks share one GPU for a functional rehearsal of the "
                          "N>1 path on a 1-GPU box (not a performance mode)")
+    ap.add_argument('--dp-mode', default='flat', choices=['flat', 'ddp'],
+                    help='N > 1: gradient averaging as ONE flat all-reduce after the backward (default; few, large collectives '
+                         'for point-to-point xGMI, no per-gradient bucket copies, a captured step with one collective on a side '
+                         'stream instead of one per bucket) or torch DDP with 64 MB buckets overlapped with the backward')
     ap.add_argument('--family-steps', type=int, default=5,
                     help='untimed eager steps after the timed region that put every library entry point on the `kernels` list '
                          '(GEMMs by role with MFMA fractions, LayerNorm / residual / column-sum / conv / BatchNorm-tail rows); 0: off')
@@ -464,7 +468,11 @@ def main():
     dp_graph = grouped and args.backend == 'nccl' and os.environ.get('VAH_DP_GRAPH', '1') != '0'
     use_graph = args.hip_graph != 'off' and not args.no_optimizer and (not grouped or dp_graph)
     side = torch.cuda.Stream() if use_graph else None
-    if grouped and use_graph:
+    sync = None
+    if grouped and args.dp_mode == 'flat':
+        # one flat all-reduce per step after the backward (data_parallel.FlatGradSync); every rank seeds its model alike
+        net, sync = model, dp.FlatGradSync(model.parameters())
+    elif grouped and use_graph:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             net = dp.wrap(model, dev, bucket_cap_mb=int(os.environ.get('VAH_DDP_BUCKET_MB', '64')))
@@ -484,6 +492,8 @@ def main():
             feats = net(x)
         loss = sum(f.float().mean() for f in feats)
         loss.backward()
+        if sync is not None:
+            sync()
         if not args.no_optimizer:
             opt.step()
         return loss
@@ -641,7 +651,7 @@ def main():
                                        ('step = fwd+bwd' if args.no_optimizer else 'step = fwd+bwd+AdamW')
                                        + (', activations kept (with_cp off)' if args.no_checkpoint else '')),
                        'global_batch': world * args.batch, 'params_M': round(n_params / 1e6, 2),
-                       'parallelism': 'dp%d' % world,
+                       'parallelism': 'dp%d' % world, 'dp_mode': (args.dp_mode if dist.is_initialized() else None),
                        'hip_graph': use_graph, 'hip_graph_probe': probe,
                        'kernel_rows': ('HIP events over %d eager steps right after the timed region (events cannot be read '
                                        'back from inside a graph)' % args.steps) if use_graph else 'HIP events inside the timed region',

@@ -1,5 +1,5 @@
 """CPU, world_size 2 over gloo: the data-parallel path (vitadapter.data_parallel: batch sharding +
-DDP gradient averaging) gives the single-process gradients of the full batch.
+gradient averaging, by DDP's buckets or by one flat all-reduce) gives the single-process gradients of the full batch.
 
 No GPU in this tier, so (for this test only) deformable attention inside the product modules is
 routed to the oracle's torch restatement and SyncBatchNorm runs in eval mode (torch's
@@ -52,7 +52,7 @@ def _loss(model, x):
     return sum(f.float().mean() for f in model(x))
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     torch.set_num_threads(2)
@@ -60,11 +60,22 @@ def _worker(rank, world, port, out_dir):
     from vitadapter import data_parallel as dp
     r, lr, w = dp.init_from_env(backend='gloo')
     assert (r, w) == (rank, world)
-    net = dp.wrap(model)
-    assert isinstance(net, torch.nn.parallel.DistributedDataParallel)
     xs = dp.shard(x, rank, world)
     assert xs.shape[0] == 2
-    _loss(net, xs).backward()
+    if mode == 'ddp':
+        net = dp.wrap(model)
+        assert isinstance(net, torch.nn.parallel.DistributedDataParallel)
+        _loss(net, xs).backward()
+    else:                                   # one flat all-reduce after the backward (what bench.py runs)
+        dp.broadcast_parameters(model)
+        sync = dp.FlatGradSync(model.parameters())
+        _loss(model, xs).backward()
+        before = {k: p.grad for k, p in model.named_parameters() if p.grad is not None}
+        sync()
+        flat_base = next(iter(before.values()))
+        assert all(p.grad is not before[k] and p.grad.shape == p.shape and p.grad._base is not None
+                   for k, p in model.named_parameters() if p.grad is not None), 'gradients are views of the flat buffer'
+        del flat_base
     t = dp.max_over_ranks(float(rank + 1), torch.device('cpu'))
     assert t == float(world)
     grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
@@ -74,9 +85,10 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(300)
-def test_two_rank_gloo_matches_single_process(tmp_path):
+@pytest.mark.parametrize('mode', ['ddp', 'flat'])
+def test_two_rank_gloo_matches_single_process(tmp_path, mode):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
     model, x = _build()
     _loss(model, x).backward()        # full batch, one process: mean over 4 images
     g0 = torch.load(os.path.join(tmp_path, 'grads_rank0.pt'), weights_only=True)

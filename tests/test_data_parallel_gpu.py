@@ -43,16 +43,21 @@ def _loss(model, x):
     return sum(f.float().mean() for f in feats)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode):
     os.environ.update(RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world),
                       MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     torch.cuda.set_device(0)
     model, x = _build()
     from vitadapter import data_parallel as dp
     dp.init_from_env(backend='gloo')
-    net = dp.wrap(model, torch.device('cuda', 0))
-    assert isinstance(net, torch.nn.parallel.DistributedDataParallel)
-    _loss(net, dp.shard(x, rank, world)).backward()
+    if mode == 'ddp':
+        net = dp.wrap(model, torch.device('cuda', 0))
+        assert isinstance(net, torch.nn.parallel.DistributedDataParallel)
+        _loss(net, dp.shard(x, rank, world)).backward()
+    else:
+        sync = dp.FlatGradSync(model.parameters())
+        _loss(model, dp.shard(x, rank, world)).backward()
+        sync()
     grads = {k: p.grad.float().cpu() for k, p in model.named_parameters() if p.grad is not None}
     stats = {k: v.float().cpu() for k, v in model.state_dict().items() if 'running_' in k}
     torch.save((grads, stats), os.path.join(out_dir, 'rank%d.pt' % rank))
@@ -61,9 +66,10 @@ def _worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_ddp_on_gpu_matches_single_process(tmp_path):
+@pytest.mark.parametrize('mode', ['ddp', 'flat'])
+def test_two_rank_ddp_on_gpu_matches_single_process(tmp_path, mode):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
     from vitadapter.data_parallel import revert_sync_batchnorm
     model, x = _build()
     model = revert_sync_batchnorm(model).cuda().train()          # one process, whole batch, plain BN
@@ -89,8 +95,9 @@ def test_two_rank_ddp_on_gpu_matches_single_process(tmp_path):
 @pytest.mark.timeout(900)
 def test_one_rank_rccl_step_with_collectives_is_captured_and_replayed(tmp_path):
     """RCCL on the one GPU of the test box: VAH_ONE_RANK_GROUP=1 makes bench.py build the nccl (= RCCL) process group, wrap
-    the backbone in DDP and run the SyncBatchNorm statistics all-reduces for ONE rank, so the step that `--gpus N` times -
-    bucketed gradient all-reduces and per-layer statistics all-reduces inside a captured HIP graph, `--hip-graph on`: a
+    the gradient averaging (the flat all-reduce bench.py defaults to, and DDP's buckets) and run the SyncBatchNorm statistics
+    all-reduces for ONE rank, so the step that `--gpus N` times - gradient and per-layer statistics all-reduces inside a
+    captured HIP graph, `--hip-graph on`: a
     capture failure is an error - runs end to end: RCCL initialisation, DDP's bucket hooks under capture, the collectives
     as graph nodes, K replays.  What one GPU cannot show is traffic between GPUs.  The replayed step must agree with the
     eager step of the same process group (same loss, both finite) and report itself as replayed."""
@@ -102,14 +109,17 @@ def test_one_rank_rccl_step_with_collectives_is_captured_and_replayed(tmp_path):
               '--steps', '3', '--warmup', '2', '--cpu-baseline', 'none', '--boundary-iters', '0', '--family-steps', '0',
               '--consumer-iters', '0']
     lines = {}
-    for mode in ('on', 'off'):
-        res = subprocess.run(common + ['--hip-graph', mode], env=env, capture_output=True, text=True, timeout=420)
+    for mode, dp_mode in (('on', 'flat'), ('on', 'ddp'), ('off', 'flat')):
+        res = subprocess.run(common + ['--hip-graph', mode, '--dp-mode', dp_mode], env=env, capture_output=True, text=True,
+                             timeout=420)
         assert res.returncode == 0, res.stderr[-3000:]
-        lines[mode] = json.loads(res.stdout.strip().splitlines()[-1])
-    on, off = lines['on'], lines['off']
-    assert on['config']['hip_graph'] is True and off['config']['hip_graph'] is False
-    assert on['config']['rccl_ranks'] == 1 and on['config']['backend'] == 'nccl' and on['n_gpus'] == 1
-    assert on['value'] > 0 and off['value'] > 0
+        lines[mode, dp_mode] = json.loads(res.stdout.strip().splitlines()[-1])
+    on, off = lines['on', 'flat'], lines['off', 'flat']
+    for key in (('on', 'flat'), ('on', 'ddp')):
+        cfg = lines[key]['config']
+        assert cfg['hip_graph'] is True and cfg['dp_mode'] == key[1], cfg
+        assert cfg['rccl_ranks'] == 1 and cfg['backend'] == 'nccl' and lines[key]['n_gpus'] == 1 and lines[key]['value'] > 0
+    assert off['config']['hip_graph'] is False and off['value'] > 0
     # (no bound on host_enqueue_ms_per_step here: a graph that holds RCCL nodes is launched in pieces - 21 of 29.8 ms on the
     # headline config, DESIGN 6 - so the replay is not free for the host the way the collective-free graph is; what the
     # replay buys is the step time: 36.0 -> 29.8 ms there)

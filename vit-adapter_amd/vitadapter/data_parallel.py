@@ -1,5 +1,6 @@
-"""Data-parallel harness of the backbone: one process per GPU, gradients all-reduced by torch
-DDP over RCCL (backend "nccl" on ROCm), SyncBatchNorm statistics exchanged per layer.
+"""Data-parallel harness of the backbone: one process per GPU, gradients averaged over RCCL (backend "nccl" on ROCm) -
+one flat all-reduce per step (FlatGradSync, what bench.py runs) or torch DDP's overlapped buckets (wrap) -, SyncBatchNorm
+statistics exchanged per layer.
 
 The reference trains the same way (torch.distributed.launch + mm* DDP wrapper,
 /root/reference/segmentation/dist_train.sh:8-9, segmentation/train.py:133,204; NCCL backend
@@ -49,6 +50,53 @@ def wrap(model, device=None, bucket_cap_mb=64):
     return torch.nn.parallel.DistributedDataParallel(
         model, device_ids=ids, bucket_cap_mb=bucket_cap_mb, gradient_as_bucket_view=True,
         broadcast_buffers=False)
+
+
+class FlatGradSync:
+    """Gradient averaging as ONE collective per step: after the backward every gradient is gathered into one flat buffer
+    (one multi-tensor copy), all-reduced in place (average), and the parameters' ``.grad`` are re-pointed at their slices
+    of it (no copy back; the optimizer reads the views).
+
+    Why not DDP here: its bucket views make autograd COPY each of the ~300 gradients into a bucket (this code's weight
+    gradients come straight out of GEMMs as fresh tensors that AccumulateGrad would otherwise just keep), its all-reduces
+    sit on ProcessGroupNCCL's side stream, and a captured step with that many cross-stream edges is launched in pieces -
+    measured with a one-rank RCCL group on ViT-Adapter-B 1024^2: 26.7 ms without a group, 29.9 ms under DDP, see DESIGN 6.
+    xGMI is point to point and ring collectives are bound per link: one 400 MB all-reduce uses every link for its whole
+    duration, which is what the hardware guide asks for (few, large collectives).  What this form gives up is the overlap
+    of communication with the backward.  ``torch.nn.parallel.DistributedDataParallel`` (``wrap``) stays available.
+
+    Every rank must build its model from the same seed or call ``broadcast_parameters`` first."""
+
+    def __init__(self, parameters, group=None):
+        self.params = [p for p in parameters if p.requires_grad]
+        self.group = group
+
+    def __call__(self):
+        world = dist.get_world_size(self.group)
+        by_dtype = {}
+        for p in self.params:
+            if p.grad is not None:
+                by_dtype.setdefault((p.grad.dtype, p.grad.device), []).append(p)
+        for params in by_dtype.values():
+            grads = [p.grad.reshape(-1) for p in params]
+            flat = torch.cat(grads)
+            if dist.get_backend(self.group) == 'nccl':
+                dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+            else:                                   # gloo has no AVG
+                dist.all_reduce(flat, group=self.group)
+                flat.div_(world)
+            off = 0
+            for p, g in zip(params, grads):
+                n = g.numel()
+                p.grad = flat[off:off + n].view_as(p)
+                off += n
+
+
+def broadcast_parameters(module, src=0, group=None):
+    """Parameters and buffers of rank ``src`` to every rank (what DDP's constructor does)."""
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src=src, group=group)
 
 
 def revert_sync_batchnorm(module):
