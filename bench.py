@@ -18,8 +18,9 @@ step) where the host is the longer pole - slow-CPU boxes, the 24-block presets -
 overlaps the weight-gradient GEMMs on a side stream, a captured graph does not).  HIP events cannot be read back from
 inside a graph, so after a replayed region the per-kernel rows are taken from K more EAGER steps of the same process
 (`config.hip_graph`, `config.hip_graph_probe`, `config.kernel_rows`).  N > 1 (round 3): the same - the captured step then
-holds DDP's bucketed all-reduces and the SyncBatchNorm statistics all-reduces (RCCL collectives are capturable; DDP is
-constructed and warmed up for 11 steps on the side stream, as torch asks); the ranks agree before the first replay, so a
+holds the gradient all-reduce (`--dp-mode flat`, default: ONE flat all-reduce after the backward; `ddp`: torch DDP's buckets,
+constructed and warmed up for 11 steps on the side stream as torch asks) and the SyncBatchNorm statistics all-reduces (RCCL
+collectives are capturable); the ranks agree before the first replay, so a
 rank whose capture failed sends everyone to the eager loop.  `--hip-graph off` / `VAH_DP_GRAPH=0` time the eager loop with
 the events inside the timed region.
 
