@@ -1,4 +1,5 @@
 #!/bin/bash
+# Round-3 acceptance loop on the GPU box: the whole -m gpu suite, then the driver-style bench line (gpurun_out/r03/)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out/r03
 cd $R
