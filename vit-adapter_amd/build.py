@@ -36,6 +36,9 @@ def _newer(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+EXTRA_FLAGS = os.environ.get('VAH_EXTRA_HIPCC_FLAGS', '').split()       # experiments (tools/ablate_tile.sh): -D switches
+
+
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     os.makedirs(LIBDIR, exist_ok=True)
@@ -47,7 +50,7 @@ def build(force=False, verbose=False):
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + '.o')
         objs.append(o)
         if force or _newer(o, [s] + hdrs):
-            cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(os.path.basename(s), []) + ['-c', s, '-o', o]
+            cmd = [HIPCC] + FLAGS + PER_FILE_FLAGS.get(os.path.basename(s), []) + EXTRA_FLAGS + ['-c', s, '-o', o]
             if verbose:
                 print(' '.join(cmd), flush=True)
             subprocess.check_call(cmd)

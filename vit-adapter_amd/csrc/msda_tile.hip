@@ -51,11 +51,19 @@
 #ifndef VAH_VF_PER_CHUNK
 #define VAH_VF_PER_CHUNK 0
 #endif
+// Timing experiments only (tools/ablate_tile.sh builds a SEPARATE library with -DVAH_TILE_ABLATE=bits; the results of
+// such a build are wrong): bit 0 skips the Wt updates, 1 the matrix phase, 2 the owned samples' dot products, 4 the
+// gradient stores, 6 the chunk loop.  Compile-time, so the shipped library has neither the branches nor a switch.
+#ifndef VAH_TILE_ABLATE
+#define VAH_TILE_ABLATE 0
+#endif
 
 namespace vah {
 namespace {
 
 using namespace vah::msda;
+
+constexpr int ablate = VAH_TILE_ABLATE;
 
 constexpr int kTW = 8, kTH = 4;    // tile: 8 x 4 pixels = the 32 columns of one 32x32 MFMA tile
 constexpr int kTShY = 2, kTShX = 3;
@@ -720,7 +728,7 @@ template <typename GT, typename OT, typename Src, bool TAPS, int WPS, bool EARLY
 __global__ __launch_bounds__(64, WPS) void msda_tile(Src src, const PlanDev *__restrict__ plan, int *__restrict__ counter,
                                                      const int *__restrict__ entries, float *__restrict__ slabs,
                                                      const ItemDesc *__restrict__ items, int items_per_xcd, int M, int Lq, int64_t S,
-                                                     const GT *__restrict__ value, const GT *__restrict__ grad_out, int ablate,
+                                                     const GT *__restrict__ value, const GT *__restrict__ grad_out,
                                                      OT *__restrict__ grad_value) {
     using LD = TileLds<GT>;
     constexpr int WS = LD::WS, DP = LD::DP;
@@ -1233,16 +1241,10 @@ int run_tiled(const char *fn, const Src &src, const Bounds &bd, const int64_t *s
     int64_t grid = waves;
     const int64_t most = N * M * bd.Tmax * kChunksPerWg;           // never more waves than the bound of items
     if (grid > most) grid = (most + 7) / 8 * 8;
-    // VAH_TILE_ABLATE (timing experiments only, results are wrong): bit 0 skips the Wt updates, 1 the matrix phase, 2 the
-    // owned samples' dot products, 4 the gradient stores, 6 the chunk loop
-    static const int ablate = [] {
-        const char *e = getenv("VAH_TILE_ABLATE");
-        return e ? atoi(e) : 0;
-    }();
     hipLaunchKernelGGL((msda_tile<GT, OT, Src, TAPS, WPS, EARLY>), dim3((unsigned)grid), dim3(64), smem, st, src, (const PlanDev *)(base + bd.off_plan),
                        (int *)(base + bd.off_counts), (const int *)(base + bd.off_entries), (float *)(base + bd.off_slabs), (const ItemDesc *)(base + bd.off_items),
                        (int)bd.items_per_xcd, (int)M, (int)Lq,
-                       S, value, grad_out, ablate, grad_value);
+                       S, value, grad_out, grad_value);
     return check_launch(fn);
 }
 
