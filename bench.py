@@ -543,8 +543,18 @@ def main():
             graph = torch.cuda.CUDAGraph()
             opt.zero_grad(set_to_none=True)
             captured, why = True, None
+            mode = 'global'
+            if grouped:
+                # ProcessGroupNCCL's watchdog thread polls the events of the eager collectives enqueued so far; an event
+                # query from ANY thread while a capture in the default (global) mode is open is an error that aborts the
+                # process (seen once in ~6 one-rank runs: WorkNCCL::finishedGPUExecutionInternal from Watchdog::runLoop).
+                # So: everything enqueued is finished and the watchdog has had time to retire it before the capture opens,
+                # and the capture only polices its own thread.
+                fence()
+                time.sleep(1.0)
+                mode = 'thread_local'
             try:
-                with torch.cuda.graph(graph):
+                with torch.cuda.graph(graph, capture_error_mode=mode):
                     graph_loss = step()
             except Exception as exc:                   # noqa: BLE001 - told to the other ranks below, then handled
                 captured, why = False, exc
