@@ -646,3 +646,57 @@ def test_patch_embed_gemm_matches_conv(B, H, W, E):
     _close(tok.float(), ref, 2 ** -7, 'tokens')
     _close(conv.weight.grad, wr.grad, 2e-3, 'd weight')
     _close(conv.bias.grad, br.grad, 2e-3, 'd bias')
+
+
+def test_drop_path_scales_are_pooled_per_forward():
+    """vitadapter/fused.py::_DropPool: from the second forward of a module on, every drop-path site of the forward is
+    served a row of ONE draw floor(keep + U) / keep (timm's DropPath formula) in the recorded order; values are 0 or
+    1 / keep with the site's own keep; a site off the recorded sequence, a module that recomputes activations, eval mode
+    and calls outside a forward epoch draw on their own."""
+    from vitadapter import fused
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(64, 64)
+            self.norm = torch.nn.LayerNorm(64)
+
+        def forward(self, x, keeps, z):
+            scales = []
+            with fused.forward_epoch(self):
+                for k in keeps:
+                    dp = torch.nn.Dropout(0)            # any object with drop_prob / training
+                    dp.drop_prob, dp.training = 1.0 - k, self.training
+                    scales.append(fused._drop_path_scale(x, dp))
+            return scales
+
+    m = Toy().cuda().train()
+    x = torch.randn(8, 16, 64, device='cuda')
+    keeps = [0.9, 0.9, 0.7, 0.5]
+    with torch.autocast('cuda', dtype=torch.bfloat16):
+        first = m(x, keeps, None)
+        assert fused.DROP_POOL.module is None and m.__dict__['_vah_drop_trace'] == [(k, 8) for k in keeps]
+        assert all(s.data_ptr() != first[0].data_ptr() for s in first[1:])            # first forward: one draw per site
+        seen = {k: set() for k in keeps}
+        for _ in range(40):
+            got = m(x, keeps, None)
+            base = got[0].data_ptr()
+            assert [s.data_ptr() - base for s in got] == [32 * i for i in range(4)]   # rows of one (4, 8) fp32 tensor
+            for k, s in zip(keeps, got):
+                vals = set(round(v, 5) for v in s.tolist())
+                assert vals <= {0.0, round(1.0 / k, 5)}, (k, vals)
+                seen[k] |= vals
+        assert all(len(v) == 2 for k, v in seen.items() if k < 0.9) and seen[0.5] == {0.0, 2.0}
+        off = m(x, [0.9, 0.6, 0.7, 0.5], None)                                        # second site differs: on-demand from there
+        assert off[1].data_ptr() - off[0].data_ptr() != 32 and set(round(v, 4) for v in off[1].tolist()) <= {0.0, round(1 / 0.6, 4)}
+        m.eval()
+        assert m(x, keeps, None) == [None] * 4
+        m.train()
+        m.with_cp = True                                                              # a module that recomputes: never pooled
+        m.__dict__.pop('vah_drop_pool_ok')
+        a = m(x, keeps, None)
+        b = m(x, keeps, None)
+        assert b[1].data_ptr() - b[0].data_ptr() != 32 and a is not b
+    dp = torch.nn.Dropout(0)
+    dp.drop_prob, dp.training = 0.5, True
+    assert fused._drop_path_scale(x, dp).shape == (8,)                                # outside an epoch: plain draw

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 import _vah
 
 ENABLED = {'pair_core': True, 'layer_norm': True, 'residual': True, 'residual_ln': True, 'dwconv': True, 'linear': True, 'bn_tail': True,
-           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True, 'maps_in': True, 'linear_pair': True, 'maxpool': True, 'conv1x1': True, 'ln_dual': True, 'wgrad_fin': True, 'spm_nhwc': True, 'up_gemm': True, 'patch_gemm': True, 'wgrad_overlap': True}
+           'bn_relu': True, 'bias_fold': True, 'keep_feat': True, 'maps': True, 'maps_in': True, 'linear_pair': True, 'maxpool': True, 'conv1x1': True, 'ln_dual': True, 'wgrad_fin': True, 'spm_nhwc': True, 'up_gemm': True, 'patch_gemm': True, 'wgrad_overlap': True, 'drop_pool': True}
 for _k in os.environ.get('VAH_FUSED_DISABLE', '').split(','):      # e.g. VAH_FUSED_DISABLE=residual_ln,bn_tail (A/B runs)
     if _k:
         ENABLED[_k.strip()] = False
@@ -214,6 +214,60 @@ class _Bf16Copies:
 BF16_COPIES = _Bf16Copies()
 
 
+class _DropPool:
+    """The per-sample drop-path scales of ONE forward from ONE random draw.  A ViT-Adapter-B step has 28 drop-path sites; as
+    `new_empty(B).bernoulli_(keep).div_(keep)` each is two 4-us kernels in a stream of much larger ones (56 launches per
+    step).  Inside a forward epoch the sites are served rows of `floor(keep_i + U[0,1)) / keep_i` - timm's own DropPath
+    formula, drawn for all sites at once - in the order the previous forward of the same module asked for them; a site
+    that does not match the recorded sequence (another batch size, another model path) ends the pooling for that forward
+    and draws on its own.  Off for modules that recompute activations (with_cp): the recomputation replays torch's RNG
+    state, which a pooled draw made at the start of the forward is not part of."""
+
+    def __init__(self):
+        self.rows = self.seq = self.module = None
+        self.pos, self.recording = 0, []
+
+    def begin(self, module, device):
+        self.module, self.recording, self.pos, self.rows = module, [], 0, None
+        d = module.__dict__
+        self.seq = d.get('_vah_drop_trace')
+        if 'vah_drop_pool_ok' not in d:
+            d['vah_drop_pool_ok'] = not any(getattr(m, 'with_cp', False) for m in module.modules())
+        if not (self.seq and d['vah_drop_pool_ok'] and ENABLED.get('drop_pool', True)):
+            self.seq = None
+            return
+        keeps = d.get('_vah_drop_keeps')
+        if keeps is None or keeps.device != device or keeps.shape[0] != len(self.seq):
+            keeps = d['_vah_drop_keeps'] = torch.tensor([k for k, _ in self.seq], dtype=torch.float32, device=device)[:, None]
+        B = self.seq[0][1]
+        if any(b != B for _, b in self.seq):
+            self.seq = None
+            return
+        self.rows = torch.rand((len(self.seq), B), device=device).add_(keeps).floor_().div_(keeps)
+
+    def take(self, x, keep):
+        B = x.shape[0]
+        if self.module is not None:
+            self.recording.append((keep, B))
+            if self.rows is not None:
+                if self.pos < len(self.seq) and self.seq[self.pos] == (keep, B) and self.rows.device == x.device:
+                    self.pos += 1
+                    return self.rows[self.pos - 1]
+                self.rows = None            # not the recorded sequence: every site of this forward draws on its own
+        return x.new_empty((B,)).bernoulli_(keep).div_(keep)
+
+    def end(self):
+        if self.module is not None:
+            d = self.module.__dict__
+            if d.get('_vah_drop_trace') != self.recording:
+                d['_vah_drop_trace'] = self.recording
+                d.pop('_vah_drop_keeps', None)
+        self.module = self.rows = self.seq = None
+
+
+DROP_POOL = _DropPool()
+
+
 class forward_epoch:
     """``with fused.forward_epoch(model): ...`` around a model's forward: on entry ONE multi-tensor cast
     makes the bf16 copies of all its fp32 nn.Linear parameters, which then serve every fused Linear of
@@ -238,10 +292,13 @@ class forward_epoch:
         if live:
             BF16_COPIES.begin(live)
             SIDE.begin_epoch()
+            if module.training:
+                DROP_POOL.begin(module, live[0].device)
         return self
 
     def __exit__(self, *exc):
         BF16_COPIES.end()
+        DROP_POOL.end()
         return False
 
 
@@ -913,8 +970,7 @@ def residual(x, z, gamma=None, drop_path=None):
             and (gamma is None or gamma.dtype == torch.float32)):
         s = None
         if prob > 0. and training:
-            keep = 1.0 - prob
-            s = x.new_empty((x.shape[0],)).bernoulli_(keep).div_(keep)
+            s = DROP_POOL.take(x, 1.0 - prob)
         return _ScaleResidual.apply(x, z, gamma, s)
     t = gamma * z if gamma is not None else z
     return x + (drop_path(t) if drop_path is not None else t)
@@ -984,8 +1040,7 @@ class _ResidualLN(torch.autograd.Function):
 def _drop_path_scale(x, drop_path):
     prob = float(getattr(drop_path, 'drop_prob', 0.) or 0.)
     if prob > 0. and bool(getattr(drop_path, 'training', False)):
-        keep = 1.0 - prob
-        return x.new_empty((x.shape[0],)).bernoulli_(keep).div_(keep)
+        return DROP_POOL.take(x, 1.0 - prob)
     return None
 
 
