@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void reduce_splits(const float *__restrict__ p
 // operands computed here (round 2 found exhaustive-mode algorithms that run without an error status and return wrong
 // numbers; round 3 found heuristic answers for 1024 x N x 64 that leave most of the output unwritten once the workspace
 // holds another product's data - and whose first 64 columns are right).  So the candidate runs twice on an output
-// filled with NaN patterns, first over a workspace filled with 0xFF, then over whatever it left there, and every element
+// filled with NaN patterns, first over a workspace filled with 0x01 bytes, then over whatever it left there, and every element
 // of both results has to agree with the reference.
 __global__ __launch_bounds__(256) void ref_gemm(int ta, int tb, int M, int N, int K, const __bf16 *__restrict__ A, int64_t lda,
                                                 const __bf16 *__restrict__ B, int64_t ldb, const void *__restrict__ bias,
@@ -307,7 +307,9 @@ bool validate(State &S, const Call &c, Problem &p, const hipblasLtMatmulAlgo_t &
     const size_t es = k.d32 ? 4 : 2;
     const int64_t MN = k.M * k.N;
     const unsigned blocks = (unsigned)std::min<int64_t>(4096, (MN + 255) / 256);
-    if (c.ws_bytes && hipMemsetAsync(c.ws, 0xFF, c.ws_bytes, c.st) != hipSuccess) return true;
+    // dirty, but not hostile: 0x01 bytes are small positive integers / denormal floats - a kernel that expects zeroed flags
+    // or partial sums goes wrong on them (and is refused below) without being handed 0xFFFFFFFF as an index
+    if (c.ws_bytes && hipMemsetAsync(c.ws, 0x01, c.ws_bytes, c.st) != hipSuccess) return true;
     for (int pass = 0; pass < 2; ++pass) {
         if (hipMemsetAsync(out2, 0, 8, c.st) != hipSuccess) return true;
         if (hipMemset2DAsync(c.D, (size_t)k.ldd * es, 0xFF, (size_t)k.N * es, (size_t)k.M, c.st) != hipSuccess) return true;
